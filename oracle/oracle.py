@@ -1,0 +1,338 @@
+"""ctypes front end of the CPU oracle (oracle/pysp_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (pysp_amd) never does.  Host-side float64 matrix construction is restated here in
+NumPy from colorize/transform.py:40-49, colorize/rgb_space.py:19-52 and wb_cct/helpers_cam_mat.py:7-20
+(all citations relative to /root/reference).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB: Optional[ctypes.CDLL] = None
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    fl = line.split()
+                    return "fma" in fl and "avx2" in fl
+    except OSError:
+        pass
+    return False
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (and nothing else) with the recipe in oracle/Makefile."""
+    if force or not (os.path.exists(os.path.join(_HERE, "liboracle.so"))
+                     and os.path.exists(os.path.join(_HERE, "liboracle_fma.so"))):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        build()
+        name = "liboracle_fma.so" if _cpu_has_fma() else "liboracle.so"
+        _LIB = ctypes.CDLL(os.path.join(_HERE, name))
+    return _LIB
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray, t=ctypes.c_float):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _chk(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side colour constants
+
+D65_XY = (0.31272, 0.32903)  # wb_cct/standard_ill.py:33
+
+
+def xy_to_XYZ(xy) -> np.ndarray:
+    """colour.xy_to_XYZ for Y=1: [x/y, 1, (1-x-y)/y] (call sites rgb_space.py:14,40; helpers_exif.py:50)."""
+    x, y = float(xy[0]), float(xy[1])
+    return np.array([x / y, 1.0, (1.0 - x - y) / y], dtype=np.float64)
+
+
+def bradford(cur_xyz, tgt_xyz) -> np.ndarray:
+    """wb_cct/helpers_cam_mat.py:7-20."""
+    m = np.array([[0.8951000, 0.2664000, -0.1614000],
+                  [-0.7502000, 1.7135000, 0.0367000],
+                  [0.0389000, -0.0685000, 1.0296000]])
+    s = np.matmul(m, tgt_xyz) / np.matmul(m, cur_xyz)
+    return np.matmul(np.linalg.inv(m), np.matmul(np.diag(s), m))
+
+
+def rec709_to_xyz(dest_white_xyz) -> np.ndarray:
+    """colorize/rgb_space.py:19-52 for REC709 (:54) adapted from D65 to dest_white_xyz."""
+    prim = ((0.64, 0.33), (0.3, 0.6), (0.15, 0.06))
+    mat = np.array([[p[0] / p[1] for p in prim], [1, 1, 1], [(1 - p[0] - p[1]) / p[1] for p in prim]], dtype=np.float64)
+    white = xy_to_XYZ(D65_XY)
+    s = np.linalg.inv(mat) @ white
+    mat[:, 0] *= s[0]
+    mat[:, 1] *= s[1]
+    mat[:, 2] *= s[2]
+    return bradford(white, np.array(dest_white_xyz, dtype=np.float64)) @ mat
+
+
+def final_matrix(xyz_to_cam: np.ndarray, cam_white_xyz) -> np.ndarray:
+    """colorize/transform.py:40-49: inv(rownorm(XYZ->cam @ sRGB->XYZ(cam white))) as float64 (3,3)."""
+    c = np.matmul(xyz_to_cam, rec709_to_xyz(np.asarray(cam_white_xyz).tolist()))
+    c = c / c.sum(axis=1)[:, np.newaxis]
+    return np.linalg.inv(c)
+
+
+def ahd_h() -> np.ndarray:
+    """ahd.py:89-94 evaluated with NumPy float32 exactly as written."""
+    h_optimal = np.array([-0.2569, 0.4339, 0.5138, 0.4339, -0.2569], dtype=np.float32)
+    h_fast = np.array([-0.25, 0.5, 0.5, 0.5, -0.25], dtype=np.float32)
+    ratio_optimal = 0.125
+    h = (h_optimal * ratio_optimal) + (h_fast * (1 - ratio_optimal))
+    return h / h.sum()
+
+
+# ----------------------------------------------------------------------------------------------
+# thin wrappers (NumPy in / NumPy out)
+
+def bayer_to_rgbg(bayer: np.ndarray):
+    H, W = bayer.shape
+    outs = [np.empty((H // 2, W // 2), np.float32) for _ in range(4)]
+    if bayer.dtype == np.uint16:
+        b = np.ascontiguousarray(bayer)
+        _chk(lib().orc_bayer_to_rgbg_u16(_p(b, ctypes.c_uint16), H, W, *[_p(o) for o in outs]), "bayer_to_rgbg")
+    else:
+        b = _f32(bayer)
+        _chk(lib().orc_bayer_to_rgbg_f32(_p(b), H, W, *[_p(o) for o in outs]), "bayer_to_rgbg")
+    return tuple(outs)
+
+
+def rgbg_to_bayer(r, g1, b, g2) -> np.ndarray:
+    r, g1, b, g2 = map(_f32, (r, g1, b, g2))
+    h, w = r.shape
+    out = np.empty((2 * h, 2 * w), np.float32)
+    _chk(lib().orc_rgbg_to_bayer_f32(_p(r), _p(g1), _p(b), _p(g2), h, w, _p(out)), "rgbg_to_bayer")
+    return out
+
+
+def bayer_normalize(bayer_u16: np.ndarray, black: Sequence[float], sat: Sequence[float]) -> np.ndarray:
+    b = np.ascontiguousarray(bayer_u16, dtype=np.uint16)
+    H, W = b.shape
+    bl, sa = _f32(black[:4]), _f32(sat[:4])
+    out = np.empty((H, W), np.float32)
+    _chk(lib().orc_bayer_normalize_u16(_p(b, ctypes.c_uint16), H, W, _p(bl), _p(sa), _p(out)), "bayer_normalize")
+    return out
+
+
+def rgb2lab(rgb: np.ndarray) -> np.ndarray:
+    a = _f32(rgb)
+    out = np.empty_like(a)
+    _chk(lib().orc_rgb2lab(_p(a), ctypes.c_size_t(a.size // 3), _p(out)), "rgb2lab")
+    return out
+
+
+def lab_pow24(u):
+    a = _f32(u); out = np.empty_like(a)
+    lib().orc_lab_pow24(_p(a), ctypes.c_size_t(a.size), _p(out)); return out
+
+
+def lab_cbrt(x):
+    a = _f32(x); out = np.empty_like(a)
+    lib().orc_lab_cbrt(_p(a), ctypes.c_size_t(a.size), _p(out)); return out
+
+
+def build_map(lab_padded: np.ndarray, k_pad: int, is_vertical: bool) -> np.ndarray:
+    a = _f32(lab_padded)
+    Hp, Wp, _ = a.shape
+    out = np.empty((Hp - 2 * k_pad, Wp - 2 * k_pad), np.float32)
+    _chk(lib().orc_build_map(_p(a), Hp, Wp, int(k_pad), int(bool(is_vertical)), _p(out)), "build_map")
+    return out
+
+
+def _plane_op(name: str, src: np.ndarray) -> np.ndarray:
+    a = _f32(src); h, w = a.shape
+    out = np.empty_like(a)
+    _chk(getattr(lib(), name)(_p(a), h, w, _p(out)), name)
+    return out
+
+
+def gaussian_blur3(src): return _plane_op("orc_gaussian_blur3", src)
+def median5(src): return _plane_op("orc_median5", src)
+def box3(src): return _plane_op("orc_box3", src)
+
+
+def filter2d_3x3(src: np.ndarray, k: np.ndarray) -> np.ndarray:
+    a = _f32(src); h, w = a.shape
+    kk = np.ascontiguousarray(k, dtype=np.float64).reshape(9)
+    out = np.empty_like(a)
+    _chk(lib().orc_filter2d_3x3(_p(a), h, w, _p(kk, ctypes.c_double), _p(out)), "filter2d")
+    return out
+
+
+def resize2x_linear(src: np.ndarray) -> np.ndarray:
+    a = _f32(src); h, w, c = a.shape
+    out = np.empty((2 * h, 2 * w, c), np.float32)
+    _chk(lib().orc_resize2x_linear(_p(a), h, w, c, _p(out)), "resize2x")
+    return out
+
+
+def get_rgbg_kernel(base_position: int):
+    k = np.empty(36, np.float64)
+    _chk(lib().orc_get_rgbg_kernel(int(base_position), _p(k, ctypes.c_double)), "get_rgbg_kernel")
+    return tuple(k.reshape(4, 3, 3))
+
+
+def resample_channel(sub, g_sub, g_hf, pos: int) -> np.ndarray:
+    sub, g_sub, g_hf = map(_f32, (sub, g_sub, g_hf))
+    h, w = sub.shape
+    out = np.empty((2 * h, 2 * w), np.float32)
+    _chk(lib().orc_resample_channel(_p(sub), _p(g_sub), _p(g_hf), h, w, int(pos), _p(out)), "resample_channel")
+    return out
+
+
+def resample_g_full(g1, g2) -> np.ndarray:
+    g1, g2 = _f32(g1), _f32(g2)
+    h, w = g1.shape
+    out = np.empty((2 * h, 2 * w), np.float32)
+    _chk(lib().orc_resample_g_full(_p(g1), _p(g2), h, w, _p(out)), "resample_g_full")
+    return out
+
+
+def demosaic_draft(bayer, wb) -> np.ndarray:
+    b = _f32(bayer); H, W = b.shape; wbf = _f32(wb[:3])
+    out = np.empty((H, W, 3), np.float32)
+    _chk(lib().orc_demosaic_draft(_p(b), H, W, _p(wbf), _p(out)), "draft")
+    return out
+
+
+def demosaic_eag(bayer, wb) -> np.ndarray:
+    b = _f32(bayer); H, W = b.shape; wbf = _f32(wb[:3])
+    out = np.empty((H, W, 3), np.float32)
+    _chk(lib().orc_demosaic_eag(_p(b), H, W, _p(wbf), _p(out)), "eag")
+    return out
+
+
+class _Taps(ctypes.Structure):
+    _fields_ = [(n, c_f32p) for n in ("g_h", "g_v", "r_h", "r_v", "b_h", "b_v", "map_h", "map_v", "pre_post")]
+
+
+def demosaic_ahd(bayer, wb, M, hdr: bool = False, stages: int = 1, taps: bool = False):
+    b = _f32(bayer); H, W = b.shape; wbf = _f32(wb[:3])
+    Mm = np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+    out = np.empty((H, W, 3), np.float32)
+    if not taps:
+        _chk(lib().orc_demosaic_ahd(_p(b), H, W, _p(wbf), _p(Mm, ctypes.c_double), int(bool(hdr)), int(stages), _p(out)), "ahd")
+        return out
+    t = {n: np.empty((H, W), np.float32) for n, _ in _Taps._fields_ if n != "pre_post"}
+    t["pre_post"] = np.empty((H, W, 3), np.float32)
+    st = _Taps(**{n: _p(a) for n, a in t.items()})
+    _chk(lib().orc_demosaic_ahd_taps(_p(b), H, W, _p(wbf), _p(Mm, ctypes.c_double), int(bool(hdr)), int(stages), _p(out),
+                                     ctypes.byref(st)), "ahd_taps")
+    return out, t
+
+
+def cam_to_rgb(rgb, M, clip: bool = True) -> np.ndarray:
+    a = _f32(rgb)
+    Mm = np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+    out = np.empty_like(a)
+    _chk(lib().orc_cam_to_rgb(_p(a), ctypes.c_size_t(a.size // 3), _p(Mm, ctypes.c_double), int(bool(clip)), _p(out)), "cam_to_rgb")
+    return out
+
+
+def _ew(name, x):
+    a = _f32(x); out = np.empty_like(a)
+    _chk(getattr(lib(), name)(_p(a), ctypes.c_size_t(a.size), _p(out)), name)
+    return out
+
+
+def clip_rgb(x): return _ew("orc_clip_rgb", x)
+def lin_srgb_to_srgb(x): return _ew("orc_lin_srgb_to_srgb", x)
+def srgb_to_lin_srgb(x): return _ew("orc_srgb_to_lin_srgb", x)
+
+
+def pipeline_srgb(bayer, wb, M, quality: int = 2, hdr: bool = False, stages: int = 1, reinhard: bool = False) -> np.ndarray:
+    b = _f32(bayer); H, W = b.shape; wbf = _f32(wb[:3])
+    Mm = np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+    out = np.empty((H, W, 3), np.float32)
+    _chk(lib().orc_pipeline_srgb(_p(b), H, W, _p(wbf), _p(Mm, ctypes.c_double), int(quality), int(bool(hdr)), int(stages),
+                                 int(bool(reinhard)), _p(out)), "pipeline_srgb")
+    return out
+
+
+def hdr_fuse_params(evs: Sequence[float], wb, target_ev: Optional[float] = None):
+    """raw_hdr.py:111-136 host part: target EV, per-frame 2**(ev-target), per-site bias, argmax."""
+    evs = [float(e) for e in evs]
+    if target_ev is None:
+        target_ev = 0
+        for e in evs:
+            target_ev += e
+        target_ev /= len(evs)
+    ev_offsets = [2 ** (e - target_ev) for e in evs]
+    wb = np.asarray(wb, dtype=np.float32)
+    site_w = np.array([wb[0], wb[1], wb[2], wb[1]], dtype=np.float32)  # r,g1,b,g2 (:130-133)
+    bias = np.stack([1.6 ** (-0.1 * np.abs(off * site_w)) for off in ev_offsets]).astype(np.float32)  # :136
+    return float(target_ev), ev_offsets, bias, int(np.argmax(ev_offsets))
+
+
+def fuse_raw(frames: Sequence[np.ndarray], evs: Sequence[float], wb, target_ev: Optional[float] = None):
+    fr = [_f32(f) for f in frames]
+    K = len(fr); H, W = fr[0].shape
+    target, offs, bias, kmax = hdr_fuse_params(evs, wb, target_ev)
+    offs32 = np.array(offs, dtype=np.float32)
+    ptrs = (c_f32p * K)(*[_p(f) for f in fr])
+    out = np.empty((H, W), np.float32); cnt = np.empty((H, W), np.int32)
+    _chk(lib().orc_fuse_raw(ptrs, K, H, W, _p(offs32), _p(np.ascontiguousarray(bias.reshape(-1))), kmax, _p(out),
+                            _p(cnt, ctypes.c_int32)), "fuse_raw")
+    return out, cnt, target, max(offs)
+
+
+def warp_table(kr0, kr1, kr2, kr3, kt0, kt1, width, height, cxn, cyn, scale, seed=None) -> np.ndarray:
+    out = np.empty((height, width, 2), np.float32)
+    sp = None
+    if seed is not None:
+        seed = _f32(seed); sp = _p(seed)
+    f = ctypes.c_float
+    _chk(lib().orc_warp_table(f(kr0), f(kr1), f(kr2), f(kr3), f(kt0), f(kt1), int(width), int(height), f(cxn), f(cyn),
+                              f(scale), sp, _p(out)), "warp_table")
+    return out
+
+
+def lanczos4_table() -> np.ndarray:
+    t = np.empty((32, 8), np.float32)
+    lib().orc_lanczos4_table(_p(t)); return t
+
+
+def remap_lanczos4(src, mapx, mapy) -> np.ndarray:
+    s, mx, my = map(_f32, (src, mapx, mapy))
+    H, W = s.shape
+    out = np.empty_like(s)
+    _chk(lib().orc_remap_lanczos4(_p(s), H, W, _p(mx), _p(my), _p(out)), "remap")
+    return out
+
+
+def warp_rectilinear(image, coeffs, centre, scale: float = 1.0) -> np.ndarray:
+    img = _f32(image).copy()
+    H, W, _ = img.shape
+    cf = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1)
+    _chk(lib().orc_warp_rectilinear(_p(img), H, W, _p(cf, ctypes.c_double), cf.size // 6, ctypes.c_double(centre[0]),
+                                    ctypes.c_double(centre[1]), ctypes.c_float(scale)), "warp_rectilinear")
+    return img

@@ -1,0 +1,93 @@
+"""CPU: cross-checks inside the oracle -- the C primitives against the independent NumPy
+restatement (oracle/cv2_restated.py), and the accuracy of the bit-defined pow/cbrt used by the
+restated RGB->Lab."""
+import numpy as np
+import pytest
+
+from oracle import cv2_restated as cv
+
+
+@pytest.fixture(scope="module")
+def img():
+    rng = np.random.default_rng(11)
+    return (rng.random((23, 31), dtype=np.float32) * 2 - 0.5).astype(np.float32)
+
+
+def test_ahd_h_constants(orc):
+    h = orc.ahd_h()
+    assert h.dtype == np.float32
+    assert [float(v).hex() for v in h] == ["-0x1.0533160000000p-2", "0x1.0000000000000p-1", "0x1.0533160000000p-1",
+                                           "0x1.0000000000000p-1", "-0x1.0533160000000p-2"]
+
+
+def test_gaussian_blur(orc, img):
+    assert np.array_equal(orc.gaussian_blur3(img), cv.GaussianBlur(img, (3, 3), 1.0))
+
+
+def test_filter2d(orc, img):
+    for pos in range(4):
+        for k in orc.get_rgbg_kernel(pos):
+            assert np.array_equal(orc.filter2d_3x3(img, k), cv.filter2D(img, -1, k))
+
+
+def test_median_box_resize(orc, img):
+    assert np.array_equal(orc.median5(img), cv.medianBlur(img, 5))
+    cnt = np.random.default_rng(1).integers(0, 10, img.shape).astype(np.float32)
+    assert np.array_equal(orc.box3(cnt), cv.blur(cnt, (3, 3)))
+    rgb = np.random.default_rng(2).random((7, 9, 3), dtype=np.float32)
+    assert np.array_equal(orc.resize2x_linear(rgb), cv.resize(rgb, (18, 14)))
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (2, 6), (4, 2), (3, 5)])
+def test_tiny_planes(orc, shape):
+    a = np.random.default_rng(5).random(shape, dtype=np.float32)
+    assert np.array_equal(orc.gaussian_blur3(a), cv.GaussianBlur(a, (3, 3), 1.0))
+    assert np.array_equal(orc.median5(a), cv.medianBlur(a, 5))
+    k = orc.get_rgbg_kernel(0)[1]
+    assert np.array_equal(orc.filter2d_3x3(a, k), cv.filter2D(a, -1, k))
+
+
+def test_remap_lanczos(orc):
+    rng = np.random.default_rng(4)
+    src = rng.random((19, 27), dtype=np.float32)
+    yy, xx = np.mgrid[0:19, 0:27].astype(np.float32)
+    mx = np.clip(xx + rng.normal(0, 1.5, xx.shape).astype(np.float32), 0, 26).astype(np.float32)
+    my = np.clip(yy + rng.normal(0, 1.5, yy.shape).astype(np.float32), 0, 18).astype(np.float32)
+    assert np.array_equal(orc.lanczos4_table(), cv._lanczos4_tab())
+    assert np.array_equal(orc.remap_lanczos4(src, mx, my), cv.remap(src, mx, my, cv.INTER_LANCZOS4))
+    ident = orc.remap_lanczos4(src, xx, yy)          # integer coordinates -> exact copy
+    assert np.array_equal(ident, src)
+
+
+def test_lab_pow_cbrt_accuracy(orc):
+    u = np.geomspace(0.0904, 1.0, 200001).astype(np.float32)
+    p = orc.lab_pow24(u)
+    assert np.max(np.abs(p / u.astype(np.float64) ** 2.4 - 1)) < 1.0e-6
+    x = np.geomspace(0.008856, 1.2, 200001).astype(np.float32)
+    c = orc.lab_cbrt(x)
+    assert np.max(np.abs(c / np.cbrt(x.astype(np.float64)) - 1)) < 6.0e-7
+
+
+def test_rgb2lab_against_closed_form(orc):
+    rng = np.random.default_rng(9)
+    rgb = (rng.random((64, 64, 3)) * 1.4 - 0.2).astype(np.float32)
+    lab = orc.rgb2lab(rgb).astype(np.float64)
+    c = np.clip(rgb.astype(np.float64), 0, 1)
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = lin @ m.T / np.array([0.950456, 1.0, 1.088754])
+    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16 / 116)
+    L = np.where(xyz[..., 1] > 0.008856, 116 * f[..., 1] - 16, 903.3 * xyz[..., 1])
+    ref = np.stack([L, 500 * (f[..., 0] - f[..., 1]), 200 * (f[..., 1] - f[..., 2])], axis=-1)
+    assert np.max(np.abs(lab - ref)) < 2e-3
+    white = orc.rgb2lab(np.ones((1, 1, 3), np.float32))
+    assert abs(white[0, 0, 0] - 100) < 1e-3 and np.max(np.abs(white[0, 0, 1:])) < 2e-2
+
+
+def test_select_ties_go_vertical(orc):
+    """ahd.py:139: H is taken only where map_h < map_v; a constant frame ties everywhere."""
+    bay = np.full((8, 8), 0.25, np.float32)
+    M = np.eye(3)
+    out, taps = orc.demosaic_ahd(bay, np.ones(3, np.float32), M, False, 0, taps=True)
+    assert np.array_equal(taps["map_h"], taps["map_v"]) and (taps["map_h"] == 9).all()
+    assert np.array_equal(out[..., 1], taps["g_v"])
