@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/s of the fused AHD demosaic + cam->sRGB path on synthetic 24 MP RGGB frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one frame of BASELINE.json configs[1]: 6000x4000 float32 RGGB mosaic, resident in HBM,
+-> QualityDemosaic.Best (AHD, postprocess_steps=1) -> to_lin_srgb (clip + float64 CCM) ->
+lin_srgb_to_srgb -> (H,W,3) float32 sRGB, resident in HBM; two kernels, one C-ABI call
+(pysp_pipeline_srgb_dev).  Frames are independent, so ranks shard frames with no data-path
+collective (weak scaling); the shared WB/CCM parameter block is broadcast from rank 0 over RCCL
+once, before the timed region.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch  # first: keeps a single HIP runtime in the process (see pysp_amd/_lib.py)
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_PX = 16          # 4 B mosaic read + 12 B RGB written
+
+WORKLOADS = {
+    # name: (H, W, quality, stages, description)
+    "ahd24": (4000, 6000, 2, 1, "24MP RGGB, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb"),
+    "eag24": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + to_lin_srgb + lin_srgb_to_srgb"),
+    "draft12": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + to_lin_srgb + lin_srgb_to_srgb"),
+}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from pysp_amd import _lib
+    from pysp_amd.colorize.transform import final_matrix
+    from pysp_amd.synth import default_wb, rggb_frame
+
+    H, W, quality, stages, desc = WORKLOADS[args.workload]
+    mp_per_frame = H * W / 1e6
+
+    # ---- shared parameters: rank 0 owns them, everyone receives them over RCCL/xGMI
+    params = torch.zeros(12, dtype=torch.float64, device=dev)
+    if rank == 0:
+        wbobj = default_wb()
+        params[:3] = torch.from_numpy(wbobj.get_reciprocal_multipliers().astype(np.float64))
+        params[3:] = torch.from_numpy(final_matrix(wbobj.get_matrix()).reshape(-1))
+    if dist is not None:
+        dist.broadcast(params, src=0)
+    p = params.cpu().numpy()
+    wb = _lib.wb3(p[:3].astype(np.float32))
+    M = _lib.mat9(p[3:])
+
+    # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
+    frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = _lib.Context(local_rank)            # own HIP stream; kernels are timed with events on THAT stream
+    L = _lib.lib()
+
+    def step(i: int) -> None:
+        f = frames[i % len(frames)]
+        _lib.check(L.pysp_pipeline_srgb_dev(ctx.handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, 0,
+                                            ctypes.c_void_p(out.data_ptr())))
+
+    def fence() -> None:
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+
+    # ---- timed region: exactly K steps; per-kernel HIP events are recorded on the launch stream
+    ctx.set_kernel_timing(True)
+    per_kernel: dict = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations: events of the last timed step, plus a few extra profiled steps for an average
+    samples: dict = {}
+    for name, ms in ctx.kernel_times():
+        samples.setdefault(name, []).append(ms)
+    for i in range(min(8, args.steps)):
+        step(i)
+        for name, ms in ctx.kernel_times():
+            samples.setdefault(name, []).append(ms)
+    ctx.set_kernel_timing(False)
+    per_kernel = {k: float(np.mean(v)) for k, v in samples.items()}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps * mp_per_frame / elapsed
+    dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
+    alg_bytes = ALG_BYTES_PER_PX * H * W
+    roofline = None
+    if dom:
+        achieved = alg_bytes / (per_kernel[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(per_kernel[dom], 4),
+                    "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
+                    "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": "AHD is float32-VALU bound (about 1.4k ops/px vs 16 B/px); the HBM fraction is reported as required, not expected to approach 1"}
+
+    cpu_baseline = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import oracle
+            sh = H // 2 - (H // 2) % 2            # bounded sample: the top half of frame 0 (about 10 s of CPU work for AHD)
+            sample = np.ascontiguousarray(frames[0][:sh].cpu().numpy())
+            Mo = p[3:].reshape(3, 3)
+            t1 = time.perf_counter()
+            oracle.pipeline_srgb(sample, p[:3].astype(np.float32), Mo, quality, False, stages, False)
+            dt = time.perf_counter() - t1
+            cpu_baseline = {"value": round(sh * W / 1e6 / dt, 3), "unit": "MP/s", "cores": os.cpu_count(), "kind": "port",
+                            "sample": f"rows 0..{sh} of frame 0 ({sh}x{W}), oracle/pysp_oracle.c with OpenMP on all cores, same path"}
+        except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
+            cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc}"}
+
+    line = {
+        "metric": "megapixels/sec AHD debayer+cam->sRGB, 24MP RGGB" if args.workload == "ahd24" else f"megapixels/sec {args.workload}",
+        "value": round(value, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "H": H, "W": W, "frames_per_rank_resident": len(frames), "sharding": "frame-parallel, no data-path collective; WB/CCM broadcast once over RCCL"},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/*
+ * pysp_hip.h -- C ABI of libpysp_hip.so, the MI355X (gfx950) implementation of bullbin/pySP's
+ * debayer -> white balance -> colour matrix -> sRGB hot path.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point names the reference
+ * interface (file:line relative to the pySP repository) it stands in for.  INTEGRATION.md shows the
+ * ctypes binding a pySP maintainer would add.
+ *
+ * Conventions
+ *   - images are row-major; float32 unless the name says otherwise; H and W are the mosaic
+ *     dimensions and must be even (2x2 CFA, RGGB order: R=(0,0) G1=(0,1) G2=(1,0) B=(1,1));
+ *   - entry points return 0 on success and a negative PYSP_E* code on failure;
+ *     pysp_last_error() returns a thread-local description of the last failure;
+ *   - "host" entry points borrow caller memory for the duration of the call (outputs are written
+ *     into caller-allocated buffers, like the np.zeros outputs of the Cython units);
+ *   - "_dev" entry points take device pointers and only enqueue work on the context's stream;
+ *   - a pysp_ctx owns one HIP stream and a grow-only device workspace; it is not thread-safe,
+ *     use one context per thread.  There is no CPU fallback: without a GPU, pysp_ctx_create fails.
+ */
+#ifndef PYSP_HIP_H
+#define PYSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYSP_ABI_VERSION 1
+
+#define PYSP_OK 0
+#define PYSP_EBADARG (-1)   /* bad shape / odd dimension / null pointer  -> ValueError          */
+#define PYSP_ENOTIMPL (-2)  /* unknown quality / CFA pattern             -> NotImplementedError */
+#define PYSP_EHIP (-3)      /* HIP runtime error                         -> RuntimeError        */
+#define PYSP_ENOMEM (-4)    /* device allocation failed                  -> MemoryError         */
+
+/* pySP const.py:3-6 QualityDemosaic */
+#define PYSP_QUALITY_DRAFT 0
+#define PYSP_QUALITY_FAST 1
+#define PYSP_QUALITY_BEST 2
+
+typedef struct pysp_ctx pysp_ctx;
+
+int pysp_abi_version(void);
+const char *pysp_last_error(void);
+int pysp_device_count(void);
+
+/* stream == NULL: the context creates (and owns) its own stream; otherwise `stream` is a hipStream_t
+ * borrowed from the caller (e.g. torch.cuda.current_stream().cuda_stream). */
+pysp_ctx *pysp_ctx_create(int device, void *stream);
+void pysp_ctx_destroy(pysp_ctx *ctx);
+int pysp_ctx_sync(pysp_ctx *ctx);
+/* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
+ * the context's stream; waits for completion). */
+int pysp_ctx_last_kernel_ms(pysp_ctx *ctx, float *ms);
+/* Per-kernel timing of the demosaic pipelines: when enabled, each kernel a *_dev / host demosaic or
+ * pipeline call enqueues is bracketed by HIP events on the context's stream.  kernel_times returns the
+ * durations (ms) and static names of the kernels of the most recent such call (waits for them). */
+int pysp_ctx_set_kernel_timing(pysp_ctx *ctx, int on);
+int pysp_ctx_kernel_times(pysp_ctx *ctx, int max_kernels, float *ms, const char **names, int *n_out);
+
+/* ---- Bayer plane helpers -------------------------------------------------------------------- */
+/* bayer_chan_mixer.py:4-21 bayer_to_rgbg (float32 or uint16 mosaic -> four float32 quarter planes) */
+int pysp_bayer_to_rgbg_f32(pysp_ctx *ctx, const float *bayer, int H, int W, float *r, float *g1, float *b, float *g2);
+int pysp_bayer_to_rgbg_u16(pysp_ctx *ctx, const uint16_t *bayer, int H, int W, float *r, float *g1, float *b, float *g2);
+/* bayer_chan_mixer.py:23-42 rgbg_to_bayer (h, w are the quarter-plane dimensions) */
+int pysp_rgbg_to_bayer_f32(pysp_ctx *ctx, const float *r, const float *g1, const float *b, const float *g2, int h, int w, float *bayer);
+/* normalization.py:4-24 bayer_normalize; black/sat indexed r,g1,b,g2 */
+int pysp_bayer_normalize_u16(pysp_ctx *ctx, const uint16_t *bayer, int H, int W, const float black[4], const float sat[4], float *out);
+
+/* ---- AHD homogeneity vote -------------------------------------------------------------------
+ * debayer/ahd_homogeneity_cython.pyx:61-68  build_map(lab, k_pad, domain_k, is_vertical)
+ * lab: (Hp,Wp,3) already padded by k_pad; out: (Hp-2k_pad, Wp-2k_pad) float32 counts.
+ * domain_k is accepted and ignored by the reference (pyx:27), so it is not part of this ABI. */
+int pysp_build_map_f32(pysp_ctx *ctx, const float *lab, int Hp, int Wp, int k_pad, int is_vertical, float *out);
+
+/* ---- Demosaic -------------------------------------------------------------------------------
+ * image.py:156-183 RawRggbBayerData.demosaic -> debayer/fast_resize.py:7-44 (Draft),
+ * debayer/edge_assisted_gaussian.py:188-201 (Fast), debayer/ahd.py:14-170 (Best).
+ *   wb  : cam_wb.get_reciprocal_multipliers()[:3] (wb_cct/cam_wb.py:236-243), float32
+ *   M   : final 3x3 cam->linear-sRGB matrix, row-major float64, built on the host exactly as
+ *         colorize/transform.py:40-49 does (only Best uses it, for the homogeneity metric)
+ *   hdr : image.get_hdr() (base_types/image_base.py:82-88); stages : postprocess_steps
+ * rgb: (H,W,3) float32, white-balanced camera RGB (RawDemosaicData.image). */
+int pysp_demosaic_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, float *rgb);
+int pysp_demosaic_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, float *d_rgb);
+
+/* ---- Colour ---------------------------------------------------------------------------------
+ * colorize/transform.py:21-53 cam_to_rgb_norm pixel step: optional clip to [0,1] (:6-19,:37-38), then
+ * out = float32(float64 dot with M) (:52-53).  npx = number of RGB pixels.  in == out is allowed. */
+int pysp_cam_to_rgb_f32(pysp_ctx *ctx, const float *in, size_t npx, const double M[9], int clip, float *out);
+int pysp_cam_to_rgb_dev(pysp_ctx *ctx, const float *d_in, size_t npx, const double M[9], int clip, float *d_out);
+/* colorize/transform.py:89-99 lin_srgb_to_srgb and :101-111 srgb_to_lin_srgb; n = number of floats */
+int pysp_lin_srgb_to_srgb_f32(pysp_ctx *ctx, const float *in, size_t n, float *out);
+int pysp_lin_srgb_to_srgb_dev(pysp_ctx *ctx, const float *d_in, size_t n, float *d_out);
+int pysp_srgb_to_lin_srgb_f32(pysp_ctx *ctx, const float *in, size_t n, float *out);
+/* base_types/image_base.py:45-60 wb_apply (image*coeff -> f32) / wb_undo (f64 divide -> f32) */
+int pysp_wb_scale_f32(pysp_ctx *ctx, const float *in, size_t npx, const float coeff[3], int undo, float *out);
+
+/* ---- Fused recipe (README.md:55-63): demosaic -> to_lin_srgb (clip on) -> [x/(1+x), README.md:157]
+ * -> lin_srgb_to_srgb, one frame, no intermediate leaves the GPU.  srgb: (H,W,3) float32. */
+int pysp_pipeline_srgb_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *srgb);
+int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *d_srgb);
+
+/* ---- HDR raw fusion -------------------------------------------------------------------------
+ * raw_hdr.py:85-158 fuse_exposures_to_raw, pixel loop :135-148.  The host computes, with NumPy as
+ * the reference does, ev_off[k] = float32(2**(ev_k-target)) (:119-121), bias[k*4+c] =
+ * float32(1.6**(-0.1*|ev_off_k*w_c|)) for CFA site c in r,g1,b,g2 order (:128-136), and
+ * kmax = argmax(ev_off) (:143).  out: (H,W) float32; count: (H,W) int32 (:123,:141). */
+int pysp_fuse_raw_f32(pysp_ctx *ctx, const float *const *frames, int K, int H, int W, const float *ev_off, const float *bias, int kmax, float *out, int32_t *count);
+int pysp_fuse_raw_dev(pysp_ctx *ctx, const float *const *d_frames, int K, int H, int W, const float *ev_off, const float *bias, int kmax, float *d_out, int32_t *d_count);
+
+/* ---- DNG WarpRectilinear --------------------------------------------------------------------
+ * dng_warp_corr/dng_warp_rectilinear_coords.pyx:67-80 compute_remapping_table and :82-96
+ * compute_offset_remapping_table (seed != NULL); table: (height,width,2) float32. */
+int pysp_warp_table_f32(pysp_ctx *ctx, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height, float cx_norm, float cy_norm, float scale, const float *seed, float *table);
+/* dng_warp_corr/chan_distortion_corr.py:86-97: per plane table -> clip -> Lanczos-4 remap, in place
+ * on an (H,W,3) image; coeffs = planes x {kr0..kr3,kt0,kt1} float64 as unpacked from the opcode. */
+int pysp_warp_rectilinear_f32(pysp_ctx *ctx, float *image, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale);
+int pysp_warp_rectilinear_dev(pysp_ctx *ctx, const float *d_in, float *d_out, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSP_HIP_H */

@@ -1,0 +1,207 @@
+"""ctypes binding of libpysp_hip.so (C ABI: include/pysp_hip.h).
+
+The HIP library is the product; there is no NumPy/CPU fallback.  If the shared object is missing
+this module raises ImportError on first use; if no GPU is present, creating a context raises
+RuntimeError.  Nothing under oracle/ is ever imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import importlib.util
+import os
+import sys
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpysp_hip.so")
+
+PYSP_OK, PYSP_EBADARG, PYSP_ENOTIMPL, PYSP_EHIP, PYSP_ENOMEM = 0, -1, -2, -3, -4
+QUALITY_DRAFT, QUALITY_FAST, QUALITY_BEST = 0, 1, 2
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_u16p = ctypes.POINTER(ctypes.c_uint16)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+_int, _sz, _flt, _dbl = ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_double
+
+_SIGNATURES = {
+    "pysp_abi_version": (_int, []),
+    "pysp_last_error": (ctypes.c_char_p, []),
+    "pysp_device_count": (_int, []),
+    "pysp_ctx_create": (_vp, [_int, _vp]),
+    "pysp_ctx_destroy": (None, [_vp]),
+    "pysp_ctx_sync": (_int, [_vp]),
+    "pysp_ctx_last_kernel_ms": (_int, [_vp, _f32p]),
+    "pysp_ctx_set_kernel_timing": (_int, [_vp, _int]),
+    "pysp_ctx_kernel_times": (_int, [_vp, _int, _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_int)]),
+    "pysp_bayer_to_rgbg_f32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
+    "pysp_bayer_to_rgbg_u16": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
+    "pysp_rgbg_to_bayer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
+    "pysp_bayer_normalize_u16": (_int, [_vp, _vp, _int, _int, _f32p, _f32p, _vp]),
+    "pysp_build_map_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "pysp_demosaic_f32": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _vp]),
+    "pysp_demosaic_dev": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _vp]),
+    "pysp_cam_to_rgb_f32": (_int, [_vp, _vp, _sz, _f64p, _int, _vp]),
+    "pysp_cam_to_rgb_dev": (_int, [_vp, _vp, _sz, _f64p, _int, _vp]),
+    "pysp_lin_srgb_to_srgb_f32": (_int, [_vp, _vp, _sz, _vp]),
+    "pysp_lin_srgb_to_srgb_dev": (_int, [_vp, _vp, _sz, _vp]),
+    "pysp_srgb_to_lin_srgb_f32": (_int, [_vp, _vp, _sz, _vp]),
+    "pysp_wb_scale_f32": (_int, [_vp, _vp, _sz, _f32p, _int, _vp]),
+    "pysp_pipeline_srgb_f32": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
+    "pysp_pipeline_srgb_dev": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
+    "pysp_fuse_raw_f32": (_int, [_vp, ctypes.POINTER(_vp), _int, _int, _int, _f32p, _f32p, _int, _vp, _vp]),
+    "pysp_fuse_raw_dev": (_int, [_vp, ctypes.POINTER(_vp), _int, _int, _int, _f32p, _f32p, _int, _vp, _vp]),
+    "pysp_warp_table_f32": (_int, [_vp, _flt, _flt, _flt, _flt, _flt, _flt, _int, _int, _flt, _flt, _flt, _vp, _vp]),
+    "pysp_warp_rectilinear_f32": (_int, [_vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt]),
+    "pysp_warp_rectilinear_dev": (_int, [_vp, _vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+_tls = threading.local()
+
+
+def _preload_hip_runtime() -> None:
+    """Keep ONE HIP runtime in the process.  PyTorch's wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) and asks for it as 'libamdhip64.so'; if /opt/rocm's copy were mapped first a
+    later `import torch` would map a second runtime.  Mapping torch's copy first (without importing
+    torch) makes both libpysp_hip.so and torch resolve to the same object, in either order."""
+    if os.environ.get("PYSP_HIP_RUNTIME", "torch") != "torch" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libpysp_hip.so (once) and type its entry points."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: build it with `make -C pysp_amd/csrc` (or __graft_entry__.build()). "
+                    "pysp_amd has no CPU fallback.")
+            _preload_hip_runtime()
+            L = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(L, name)      # AttributeError here = ABI mismatch, fail loudly
+                fn.restype = res
+                fn.argtypes = args
+            if L.pysp_abi_version() != 1:
+                raise ImportError("libpysp_hip.so ABI version mismatch")
+            _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def last_error() -> str:
+    return lib().pysp_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map C return codes to the exceptions the reference raises."""
+    if rc == PYSP_OK:
+        return
+    msg = last_error()
+    if rc == PYSP_EBADARG:
+        raise ValueError(msg)
+    if rc == PYSP_ENOTIMPL:
+        raise NotImplementedError(msg)
+    if rc == PYSP_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+class Context:
+    """One HIP stream + grow-only device workspace (pysp_ctx).  Not thread-safe: one per thread."""
+
+    def __init__(self, device: int = 0, stream: int = 0):
+        self._h = lib().pysp_ctx_create(int(device), ctypes.c_void_p(stream or None))
+        if not self._h:
+            raise RuntimeError(f"pysp_ctx_create failed: {last_error()}")
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return ctypes.c_void_p(self._h)
+
+    def sync(self) -> None:
+        check(lib().pysp_ctx_sync(self.handle))
+
+    def last_kernel_ms(self) -> float:
+        ms = ctypes.c_float()
+        check(lib().pysp_ctx_last_kernel_ms(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def set_kernel_timing(self, on: bool) -> None:
+        check(lib().pysp_ctx_set_kernel_timing(self.handle, int(bool(on))))
+
+    def kernel_times(self):
+        """[(kernel name, ms), ...] of the most recent demosaic/pipeline call (kernel timing must be on)."""
+        ms = (ctypes.c_float * 8)()
+        names = (ctypes.c_char_p * 8)()
+        n = ctypes.c_int()
+        check(lib().pysp_ctx_kernel_times(self.handle, 8, ms, names, ctypes.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().pysp_ctx_destroy(ctypes.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_context() -> Context:
+    """Per-thread default context on device PYSP_DEVICE (default 0)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = Context(int(os.environ.get("PYSP_DEVICE", "0")))
+        _tls.ctx = ctx
+    return ctx
+
+
+# ---- small marshalling helpers -----------------------------------------------------------------
+def ptr(a: np.ndarray) -> ctypes.c_void_p:
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def wb3(wb) -> "ctypes.Array":
+    w = np.asarray(wb, dtype=np.float32).reshape(-1)
+    if w.size < 3:
+        raise ValueError("white-balance coefficients need at least 3 entries")
+    return (ctypes.c_float * 3)(*[float(x) for x in w[:3]])
+
+
+def mat9(M) -> "Optional[ctypes.Array]":
+    if M is None:
+        return None
+    m = np.asarray(M, dtype=np.float64).reshape(-1)
+    if m.size != 9:
+        raise ValueError("colour matrix must be 3x3")
+    return (ctypes.c_double * 9)(*[float(x) for x in m])

@@ -1,0 +1,75 @@
+"""Camera RGB -> linear sRGB -> sRGB on the GPU (reference colorize/transform.py:6-111).
+
+The 3x3 is assembled on the host in float64 exactly as transform.py:40-49 does; the per-pixel work
+(clip, float64 dot, float32 rounding, gamma) runs in HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from ..wb_cct.helpers_cam_mat import MatXyzToCamera
+from .rgb_space import ArbitraryRgbColorspace, LinRgbColorspace
+
+
+def final_matrix(cam_xyz_matrix: MatXyzToCamera, destination_colorspace: ArbitraryRgbColorspace = LinRgbColorspace.REC709) -> np.ndarray:
+    """inv(row-normalised(XYZ->cam @ RGB->XYZ adapted to the camera white)), float64 (transform.py:40-49)."""
+    to_xyz = destination_colorspace.mat_to_xyz(cam_xyz_matrix.xyz.tolist())
+    m = np.matmul(cam_xyz_matrix.mat, to_xyz)
+    m = m / m.sum(axis=1)[:, np.newaxis]        # neutral in -> neutral out
+    return np.linalg.inv(m)
+
+
+def _rgb_image(rgb: np.ndarray) -> np.ndarray:
+    a = _lib.f32c(rgb)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("expected an (H, W, 3) RGB image")
+    return a
+
+
+def clip_rgb(rgb: np.ndarray) -> np.ndarray:
+    """Clip to [0,1] (transform.py:6-19).  Pure copy semantics; done on the host, it is never the bottleneck."""
+    return np.clip(_rgb_image(rgb), 0, 1)
+
+
+def cam_to_rgb_norm(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, destination_colorspace: ArbitraryRgbColorspace,
+                    clip_highlights: bool = True) -> np.ndarray:
+    a = _rgb_image(rgb)
+    M = final_matrix(cam_xyz_matrix, destination_colorspace)
+    out = np.empty_like(a)
+    _lib.check(_lib.lib().pysp_cam_to_rgb_f32(_lib.default_context().handle, _lib.ptr(a), a.size // 3, _lib.mat9(M),
+                                              int(bool(clip_highlights)), _lib.ptr(out)))
+    return out
+
+
+def cam_to_lin_srgb(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, clip_highlights: bool = True) -> np.ndarray:
+    return cam_to_rgb_norm(rgb, cam_xyz_matrix, LinRgbColorspace.REC709, clip_highlights)
+
+
+def cam_to_clean_xyz(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, pcs_colorspace: ArbitraryRgbColorspace = LinRgbColorspace.REC2020,
+                     clip_highlights: bool = True) -> np.ndarray:
+    """transform.py:55-74: detinted working RGB, then that space's RGB->XYZ (second float64 dot)."""
+    work = cam_to_rgb_norm(rgb, cam_xyz_matrix, pcs_colorspace, clip_highlights)
+    out = np.empty_like(work)
+    _lib.check(_lib.lib().pysp_cam_to_rgb_f32(_lib.default_context().handle, _lib.ptr(work), work.size // 3,
+                                              _lib.mat9(pcs_colorspace.mat_to_xyz()), 0, _lib.ptr(out)))
+    return out
+
+
+def _flat(fn_name: str, x: np.ndarray) -> np.ndarray:
+    a = _lib.f32c(x)
+    out = np.empty_like(a)
+    _lib.check(getattr(_lib.lib(), fn_name)(_lib.default_context().handle, _lib.ptr(a), ctypes.c_size_t(a.size), _lib.ptr(out)))
+    return out
+
+
+def lin_srgb_to_srgb(rgb: np.ndarray) -> np.ndarray:
+    """Clip to [0,1] and apply the sRGB transfer curve (transform.py:89-99)."""
+    return _flat("pysp_lin_srgb_to_srgb_f32", _rgb_image(rgb))
+
+
+def srgb_to_lin_srgb(srgb: np.ndarray) -> np.ndarray:
+    """Clip to [0,1] and remove the sRGB transfer curve (transform.py:101-111)."""
+    return _flat("pysp_srgb_to_lin_srgb_f32", _rgb_image(srgb))

@@ -1,0 +1,409 @@
+// api.cpp -- the C ABI of libpysp_hip.so (include/pysp_hip.h): context, device workspace,
+// host-buffer entry points (copy in, run the kernels, copy out) and device-buffer entry points.
+// There is no CPU fallback anywhere in this file: every entry point needs a live HIP device.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/pysp_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? PYSP_ENOMEM : PYSP_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define LAUNCH_TRY(expr)                                                                           \
+    do {                                                                                           \
+        int _r = (expr);                                                                           \
+        if (_r == -1) return fail(PYSP_EBADARG, "%s: bad argument (shape/alignment)", #expr);      \
+        if (_r != 0) return fail(PYSP_EHIP, "%s: %s", #expr, hipGetErrorString(hipGetLastError())); \
+    } while (0)
+
+bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1); }
+
+}  // namespace
+
+// Grow-only device buffers, reused across calls (slots are independent).
+struct pysp_ctx {
+    pysp_ctx() { for (auto& e : tl.ev) e = nullptr; }
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    static constexpr int NSLOT = 24;
+    void* slot[NSLOT] = {};
+    size_t cap[NSLOT] = {};
+    float* lanczos = nullptr;
+    Timeline tl;
+
+    int reserve(int i, size_t bytes, void** out) {
+        if (bytes > cap[i]) {
+            if (slot[i]) { hipError_t e = hipFree(slot[i]); (void)e; slot[i] = nullptr; cap[i] = 0; }
+            size_t want = (bytes + 255) & ~(size_t)255;
+            hipError_t e = hipMalloc(&slot[i], want);
+            if (e != hipSuccess) return fail(PYSP_ENOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+            cap[i] = want;
+        }
+        *out = slot[i];
+        return PYSP_OK;
+    }
+    void tic() { tl.n = 0; if (hipEventRecord(ev0, stream) == hipSuccess) timed = false; }
+    void toc() { if (hipEventRecord(ev1, stream) == hipSuccess) timed = true; }
+};
+
+#define CTX_ENTER(ctx)                                                   \
+    if (!(ctx)) return fail(PYSP_EBADARG, "null context");               \
+    HIP_TRY(hipSetDevice((ctx)->device))
+
+#define RESERVE(ctx, i, bytes, ptr)                                      \
+    do { void* _p; int _r = (ctx)->reserve((i), (bytes), &_p); if (_r) return _r; (ptr) = reinterpret_cast<decltype(ptr)>(_p); } while (0)
+
+extern "C" {
+
+int pysp_abi_version(void) { return PYSP_ABI_VERSION; }
+const char* pysp_last_error(void) { return g_err; }
+
+int pysp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+pysp_ctx* pysp_ctx_create(int device, void* stream) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(PYSP_EHIP, "no HIP device available (%s); libpysp_hip has no CPU fallback", hipGetErrorString(e)); return nullptr; }
+    if (device < 0 || device >= n) { fail(PYSP_EBADARG, "device %d out of range [0,%d)", device, n); return nullptr; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { fail(PYSP_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
+    pysp_ctx* c = new pysp_ctx();
+    c->device = device;
+    if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
+    else {
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { fail(PYSP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr; }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { fail(PYSP_EHIP, "hipEventCreate failed"); pysp_ctx_destroy(c); return nullptr; }
+    for (int i = 0; i < 2 * Timeline::MAXK; i++)
+        if (hipEventCreate(&c->tl.ev[i]) != hipSuccess) { c->tl.ev[i] = nullptr; fail(PYSP_EHIP, "hipEventCreate failed"); pysp_ctx_destroy(c); return nullptr; }
+    float tab[256];
+    host_lanczos4_table(tab);
+    if (hipMalloc(reinterpret_cast<void**>(&c->lanczos), sizeof(tab)) != hipSuccess ||
+        hipMemcpy(c->lanczos, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "lanczos table upload failed"); pysp_ctx_destroy(c); return nullptr; }
+    return c;
+}
+
+void pysp_ctx_destroy(pysp_ctx* c) {
+    if (!c) return;
+    hipError_t e = hipSetDevice(c->device); (void)e;
+    if (c->stream) { e = hipStreamSynchronize(c->stream); (void)e; }
+    for (int i = 0; i < pysp_ctx::NSLOT; i++) if (c->slot[i]) { e = hipFree(c->slot[i]); (void)e; }
+    if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
+    for (int i = 0; i < 2 * Timeline::MAXK; i++) if (c->tl.ev[i]) { e = hipEventDestroy(c->tl.ev[i]); (void)e; }
+    if (c->ev0) { e = hipEventDestroy(c->ev0); (void)e; }
+    if (c->ev1) { e = hipEventDestroy(c->ev1); (void)e; }
+    if (c->own_stream && c->stream) { e = hipStreamDestroy(c->stream); (void)e; }
+    delete c;
+}
+
+int pysp_ctx_sync(pysp_ctx* ctx) {
+    CTX_ENTER(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PYSP_OK;
+}
+
+int pysp_ctx_last_kernel_ms(pysp_ctx* ctx, float* ms) {
+    CTX_ENTER(ctx);
+    if (!ms) return fail(PYSP_EBADARG, "null ms");
+    if (!ctx->timed) return fail(PYSP_EBADARG, "no timed call on this context yet");
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return PYSP_OK;
+}
+
+int pysp_ctx_set_kernel_timing(pysp_ctx* ctx, int on) {
+    CTX_ENTER(ctx);
+    ctx->tl.on = on != 0;
+    ctx->tl.n = 0;
+    return PYSP_OK;
+}
+
+int pysp_ctx_kernel_times(pysp_ctx* ctx, int max_kernels, float* ms, const char** names, int* n_out) {
+    CTX_ENTER(ctx);
+    if (!ms || !n_out || max_kernels < 0) return fail(PYSP_EBADARG, "kernel_times: null pointer");
+    int n = ctx->tl.n < max_kernels ? ctx->tl.n : max_kernels;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipEventSynchronize(ctx->tl.ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], ctx->tl.ev[2 * i], ctx->tl.ev[2 * i + 1]));
+        if (names) names[i] = ctx->tl.name[i];
+    }
+    *n_out = n;
+    return PYSP_OK;
+}
+
+// ---- helpers ------------------------------------------------------------------------------------
+static int h2d(pysp_ctx* c, void* d, const void* h, size_t n) { HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); return PYSP_OK; }
+static int d2h(pysp_ctx* c, void* h, const void* d, size_t n) { HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream)); return PYSP_OK; }
+#define TRY(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+
+// slots: 0 input A, 1 output A, 2/3 AHD scratch, 4..7 planes, 8 aux, 9.. HDR frames
+enum { S_IN = 0, S_OUT = 1, S_TMP0 = 2, S_TMP1 = 3, S_P0 = 4, S_AUX = 8, S_FR0 = 9 };
+
+// ---- Bayer helpers --------------------------------------------------------------------------------
+extern "C++" template <typename T>
+static int demux_host(pysp_ctx* ctx, const T* bayer, int H, int W, float* r, float* g1, float* b, float* g2) {
+    CTX_ENTER(ctx);
+    if (!bayer || !r || !g1 || !b || !g2 || !even_dims(H, W)) return fail(PYSP_EBADARG, "bayer_to_rgbg: need non-null buffers and even H,W >= 2 (got %dx%d)", H, W);
+    size_t N = (size_t)H * W, n = N / 4;
+    T* d_in; float* d_p[4];
+    RESERVE(ctx, S_IN, N * sizeof(T), d_in);
+    for (int i = 0; i < 4; i++) RESERVE(ctx, S_P0 + i, n * 4, d_p[i]);
+    TRY(h2d(ctx, d_in, bayer, N * sizeof(T)));
+    ctx->tic();
+    if (sizeof(T) == 2) LAUNCH_TRY(launch_demux_u16(ctx->stream, reinterpret_cast<const uint16_t*>(d_in), H, W, d_p[0], d_p[1], d_p[2], d_p[3]));
+    else LAUNCH_TRY(launch_demux_f32(ctx->stream, reinterpret_cast<const float*>(d_in), H, W, d_p[0], d_p[1], d_p[2], d_p[3]));
+    ctx->toc();
+    float* outs[4] = {r, g1, b, g2};
+    for (int i = 0; i < 4; i++) TRY(d2h(ctx, outs[i], d_p[i], n * 4));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_bayer_to_rgbg_f32(pysp_ctx* ctx, const float* bayer, int H, int W, float* r, float* g1, float* b, float* g2) { return demux_host(ctx, bayer, H, W, r, g1, b, g2); }
+int pysp_bayer_to_rgbg_u16(pysp_ctx* ctx, const uint16_t* bayer, int H, int W, float* r, float* g1, float* b, float* g2) { return demux_host(ctx, bayer, H, W, r, g1, b, g2); }
+
+int pysp_rgbg_to_bayer_f32(pysp_ctx* ctx, const float* r, const float* g1, const float* b, const float* g2, int h, int w, float* bayer) {
+    CTX_ENTER(ctx);
+    if (!bayer || !r || !g1 || !b || !g2 || h < 1 || w < 1) return fail(PYSP_EBADARG, "rgbg_to_bayer: bad arguments");
+    size_t n = (size_t)h * w;
+    float* d_p[4]; float* d_out;
+    const float* ins[4] = {r, g1, b, g2};
+    for (int i = 0; i < 4; i++) { RESERVE(ctx, S_P0 + i, n * 4, d_p[i]); TRY(h2d(ctx, d_p[i], ins[i], n * 4)); }
+    RESERVE(ctx, S_OUT, n * 16, d_out);
+    ctx->tic();
+    LAUNCH_TRY(launch_remux_f32(ctx->stream, d_p[0], d_p[1], d_p[2], d_p[3], h, w, d_out));
+    ctx->toc();
+    TRY(d2h(ctx, bayer, d_out, n * 16));
+    return pysp_ctx_sync(ctx);
+}
+
+int pysp_bayer_normalize_u16(pysp_ctx* ctx, const uint16_t* bayer, int H, int W, const float black[4], const float sat[4], float* out) {
+    CTX_ENTER(ctx);
+    if (!bayer || !out || !black || !sat || !even_dims(H, W)) return fail(PYSP_EBADARG, "bayer_normalize: need even H,W >= 2 (got %dx%d)", H, W);
+    size_t N = (size_t)H * W;
+    uint16_t* d_in; float* d_out;
+    RESERVE(ctx, S_IN, N * 2, d_in); RESERVE(ctx, S_OUT, N * 4, d_out);
+    TRY(h2d(ctx, d_in, bayer, N * 2));
+    ctx->tic();
+    LAUNCH_TRY(launch_normalize_u16(ctx->stream, d_in, H, W, black, sat, d_out));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, N * 4));
+    return pysp_ctx_sync(ctx);
+}
+
+int pysp_build_map_f32(pysp_ctx* ctx, const float* lab, int Hp, int Wp, int k_pad, int is_vertical, float* out) {
+    CTX_ENTER(ctx);
+    if (!lab || !out || k_pad < 1 || Hp - 2 * k_pad < 1 || Wp - 2 * k_pad < 1) return fail(PYSP_EBADARG, "build_map: bad shape (%d,%d,3) for k_pad %d", Hp, Wp, k_pad);
+    size_t nin = (size_t)Hp * Wp * 3, nout = (size_t)(Hp - 2 * k_pad) * (Wp - 2 * k_pad);
+    float *d_in, *d_out;
+    RESERVE(ctx, S_IN, nin * 4, d_in); RESERVE(ctx, S_OUT, nout * 4, d_out);
+    TRY(h2d(ctx, d_in, lab, nin * 4));
+    ctx->tic();
+    LAUNCH_TRY(launch_build_map(ctx->stream, d_in, Hp, Wp, k_pad, is_vertical != 0, d_out));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, nout * 4));
+    return pysp_ctx_sync(ctx);
+}
+
+// ---- demosaic / fused pipeline ----------------------------------------------------------------------
+static int run_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
+                            int stages, int tail, float* d_out) {
+    if (!d_bayer || !d_out || !wb) return fail(PYSP_EBADARG, "demosaic: null pointer");
+    if (!even_dims(H, W)) return fail(PYSP_EBADARG, "demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
+    static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!M) {
+        if (quality == PYSP_QUALITY_BEST || tail) return fail(PYSP_EBADARG, "demosaic: colour matrix required");
+        M = ident;
+    }
+    ctx->tic();
+    if (quality == PYSP_QUALITY_BEST) {
+        float *t0 = nullptr, *t1 = nullptr;
+        size_t bytes = (size_t)H * W * 12;
+        if (stages >= 1) RESERVE(ctx, S_TMP0, bytes, t0);
+        if (stages >= 2) RESERVE(ctx, S_TMP1, bytes, t1);
+        LAUNCH_TRY(launch_ahd(ctx->stream, d_bayer, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, &ctx->tl));
+    } else if (quality == PYSP_QUALITY_FAST) {
+        LAUNCH_TRY(launch_eag(ctx->stream, d_bayer, H, W, wb, M, tail, d_out, &ctx->tl));
+    } else if (quality == PYSP_QUALITY_DRAFT) {
+        LAUNCH_TRY(launch_draft(ctx->stream, d_bayer, H, W, wb, M, tail, d_out, &ctx->tl));
+    } else {
+        return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
+    }
+    ctx->toc();
+    return PYSP_OK;
+}
+static int run_pipeline_host(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
+                             int stages, int tail, float* out) {
+    if (!bayer || !out) return fail(PYSP_EBADARG, "demosaic: null pointer");
+    if (!even_dims(H, W)) return fail(PYSP_EBADARG, "demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
+    size_t N = (size_t)H * W;
+    float *d_in, *d_out;
+    RESERVE(ctx, S_IN, N * 4, d_in); RESERVE(ctx, S_OUT, N * 12, d_out);
+    TRY(h2d(ctx, d_in, bayer, N * 4));
+    TRY(run_pipeline_dev(ctx, d_in, H, W, wb, M, quality, hdr, stages, tail, d_out));
+    TRY(d2h(ctx, out, d_out, N * 12));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_demosaic_f32(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, float* rgb) {
+    CTX_ENTER(ctx);
+    return run_pipeline_host(ctx, bayer, H, W, wb, M, quality, hdr, stages, 0, rgb);
+}
+int pysp_demosaic_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, float* d_rgb) {
+    CTX_ENTER(ctx);
+    return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, 0, d_rgb);
+}
+int pysp_pipeline_srgb_f32(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float* srgb) {
+    CTX_ENTER(ctx);
+    return run_pipeline_host(ctx, bayer, H, W, wb, M, quality, hdr, stages, reinhard ? 3 : 2, srgb);
+}
+int pysp_pipeline_srgb_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float* d_srgb) {
+    CTX_ENTER(ctx);
+    return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, reinhard ? 3 : 2, d_srgb);
+}
+
+// ---- colour ---------------------------------------------------------------------------------------
+extern "C++" template <typename L>
+static int pointwise_host(pysp_ctx* ctx, const float* in, size_t nfloats, float* out, L launch) {
+    if (!in || !out) return fail(PYSP_EBADARG, "null pointer");
+    if (nfloats == 0) return PYSP_OK;
+    float *d_in, *d_out;
+    RESERVE(ctx, S_IN, nfloats * 4, d_in); RESERVE(ctx, S_OUT, nfloats * 4, d_out);
+    TRY(h2d(ctx, d_in, in, nfloats * 4));
+    ctx->tic();
+    LAUNCH_TRY(launch(d_in, d_out));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, nfloats * 4));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_cam_to_rgb_f32(pysp_ctx* ctx, const float* in, size_t npx, const double M[9], int clip, float* out) {
+    CTX_ENTER(ctx);
+    if (!M) return fail(PYSP_EBADARG, "cam_to_rgb: null matrix");
+    return pointwise_host(ctx, in, npx * 3, out, [&](const float* a, float* b) { return launch_cam_to_rgb(ctx->stream, a, npx, M, clip, b); });
+}
+int pysp_cam_to_rgb_dev(pysp_ctx* ctx, const float* d_in, size_t npx, const double M[9], int clip, float* d_out) {
+    CTX_ENTER(ctx);
+    if (!M || !d_in || !d_out) return fail(PYSP_EBADARG, "cam_to_rgb: null pointer");
+    ctx->tic();
+    LAUNCH_TRY(launch_cam_to_rgb(ctx->stream, d_in, npx, M, clip, d_out));
+    ctx->toc();
+    return PYSP_OK;
+}
+int pysp_lin_srgb_to_srgb_f32(pysp_ctx* ctx, const float* in, size_t n, float* out) {
+    CTX_ENTER(ctx);
+    return pointwise_host(ctx, in, n, out, [&](const float* a, float* b) { return launch_gamma(ctx->stream, a, n, 0, b); });
+}
+int pysp_lin_srgb_to_srgb_dev(pysp_ctx* ctx, const float* d_in, size_t n, float* d_out) {
+    CTX_ENTER(ctx);
+    if (!d_in || !d_out) return fail(PYSP_EBADARG, "lin_srgb_to_srgb: null pointer");
+    ctx->tic();
+    LAUNCH_TRY(launch_gamma(ctx->stream, d_in, n, 0, d_out));
+    ctx->toc();
+    return PYSP_OK;
+}
+int pysp_srgb_to_lin_srgb_f32(pysp_ctx* ctx, const float* in, size_t n, float* out) {
+    CTX_ENTER(ctx);
+    return pointwise_host(ctx, in, n, out, [&](const float* a, float* b) { return launch_gamma(ctx->stream, a, n, 1, b); });
+}
+int pysp_wb_scale_f32(pysp_ctx* ctx, const float* in, size_t npx, const float coeff[3], int undo, float* out) {
+    CTX_ENTER(ctx);
+    if (!coeff) return fail(PYSP_EBADARG, "wb_scale: null coefficients");
+    return pointwise_host(ctx, in, npx * 3, out, [&](const float* a, float* b) { return launch_wb_scale(ctx->stream, a, npx, coeff, undo, b); });
+}
+
+// ---- HDR raw fusion -----------------------------------------------------------------------------------
+int pysp_fuse_raw_dev(pysp_ctx* ctx, const float* const* d_frames, int K, int H, int W, const float* ev_off, const float* bias, int kmax, float* d_out, int32_t* d_count) {
+    CTX_ENTER(ctx);
+    if (!d_frames || !ev_off || !bias || !d_out || !d_count) return fail(PYSP_EBADARG, "fuse_raw: null pointer");
+    if (K < 1 || K > 16) return fail(PYSP_EBADARG, "fuse_raw: 1..16 exposures supported (got %d)", K);
+    if (!even_dims(H, W) || kmax < 0 || kmax >= K) return fail(PYSP_EBADARG, "fuse_raw: bad shape %dx%d or kmax %d", H, W, kmax);
+    ctx->tic();
+    LAUNCH_TRY(launch_fuse_raw(ctx->stream, d_frames, K, H, W, ev_off, bias, kmax, d_out, d_count));
+    ctx->toc();
+    return PYSP_OK;
+}
+int pysp_fuse_raw_f32(pysp_ctx* ctx, const float* const* frames, int K, int H, int W, const float* ev_off, const float* bias, int kmax, float* out, int32_t* count) {
+    CTX_ENTER(ctx);
+    if (!frames || !out || !count) return fail(PYSP_EBADARG, "fuse_raw: null pointer");
+    if (K < 1 || K > 16) return fail(PYSP_EBADARG, "fuse_raw: 1..16 exposures supported (got %d)", K);
+    if (!even_dims(H, W)) return fail(PYSP_EBADARG, "fuse_raw: bad shape %dx%d", H, W);
+    size_t N = (size_t)H * W;
+    std::vector<const float*> d_fr(K);
+    if (S_FR0 + K > pysp_ctx::NSLOT) return fail(PYSP_EBADARG, "fuse_raw: too many exposures");
+    for (int k = 0; k < K; k++) {
+        float* d; RESERVE(ctx, S_FR0 + k, N * 4, d);
+        if (!frames[k]) return fail(PYSP_EBADARG, "fuse_raw: null frame %d", k);
+        TRY(h2d(ctx, d, frames[k], N * 4));
+        d_fr[k] = d;
+    }
+    float* d_out; int32_t* d_cnt;
+    RESERVE(ctx, S_OUT, N * 4, d_out); RESERVE(ctx, S_AUX, N * 4, d_cnt);
+    TRY(pysp_fuse_raw_dev(ctx, d_fr.data(), K, H, W, ev_off, bias, kmax, d_out, d_cnt));
+    TRY(d2h(ctx, out, d_out, N * 4));
+    TRY(d2h(ctx, count, d_cnt, N * 4));
+    return pysp_ctx_sync(ctx);
+}
+
+// ---- WarpRectilinear ----------------------------------------------------------------------------------
+int pysp_warp_table_f32(pysp_ctx* ctx, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height, float cx_norm,
+                        float cy_norm, float scale, const float* seed, float* table) {
+    CTX_ENTER(ctx);
+    if (!table || width < 1 || height < 1) return fail(PYSP_EBADARG, "warp_table: bad arguments");
+    size_t n = (size_t)width * height * 2;
+    float *d_seed = nullptr, *d_tab;
+    RESERVE(ctx, S_OUT, n * 4, d_tab);
+    if (seed) { RESERVE(ctx, S_IN, n * 4, d_seed); TRY(h2d(ctx, d_seed, seed, n * 4)); }
+    ctx->tic();
+    LAUNCH_TRY(launch_warp_table(ctx->stream, kr0, kr1, kr2, kr3, kt0, kt1, width, height, cx_norm, cy_norm, scale, d_seed, d_tab));
+    ctx->toc();
+    TRY(d2h(ctx, table, d_tab, n * 4));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_warp_rectilinear_dev(pysp_ctx* ctx, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale) {
+    CTX_ENTER(ctx);
+    if (!d_in || !d_out || !coeffs || d_in == d_out) return fail(PYSP_EBADARG, "warp_rectilinear: null or aliased buffers");
+    if (planes != 3 || H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_rectilinear: plane count %d does not match a 3-channel image", planes);
+    ctx->tic();
+    LAUNCH_TRY(launch_warp_remap(ctx->stream, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale, ctx->lanczos));
+    ctx->toc();
+    return PYSP_OK;
+}
+int pysp_warp_rectilinear_f32(pysp_ctx* ctx, float* image, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale) {
+    CTX_ENTER(ctx);
+    if (!image) return fail(PYSP_EBADARG, "warp_rectilinear: null image");
+    if (H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_rectilinear: bad shape");
+    size_t n = (size_t)H * W * 3;
+    float *d_in, *d_out;
+    RESERVE(ctx, S_IN, n * 4, d_in); RESERVE(ctx, S_OUT, n * 4, d_out);
+    TRY(h2d(ctx, d_in, image, n * 4));
+    TRY(pysp_warp_rectilinear_dev(ctx, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale));
+    TRY(d2h(ctx, image, d_out, n * 4));
+    return pysp_ctx_sync(ctx);
+}
+
+}  // extern "C"

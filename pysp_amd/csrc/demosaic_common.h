@@ -1,0 +1,69 @@
+// demosaic_common.h -- device helpers shared by the AHD and EAG tile kernels:
+// the four photosite-aware 3x3 kernels of get_rgbg_kernel (debayer/gaussian.py:19-54) applied as
+// cv2.filter2D does (edge_assisted_gaussian.py:141,143), and g - GaussianBlur3(g) on a quad.
+#pragma once
+#include "devmath.h"
+
+constexpr float GK0 = 0.45186276f, GK1 = 0.27406862f;   // GaussianBlur((3,3), 1.0) taps
+
+struct Win3 { float v[3][3]; };
+
+template <int STRIDE>
+DEVI Win3 load_win(const float* plane, int gy, int gx) {
+    Win3 w;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) w.v[r][c] = plane[(gy - 1 + r) * STRIDE + (gx - 1 + c)];
+    return w;
+}
+
+// cv2.filter2D with the four photosite kernels of get_rgbg_kernel (gaussian.py:19-54): non-zero taps
+// in row-major order, accumulated from 0.0f.  o[0..3] = TL, TR, BL, BR target pixel of the quad.
+DEVI void filt_base_tl(const Win3& w, float o[4]) {  // base position TOP_LEFT (red)
+    float s;
+    s = 0.0f; s = s + 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; s = s + 0.015625f * w.v[0][2];
+    s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
+    s = s + 0.015625f * w.v[2][0]; s = s + 0.09375f * w.v[2][1]; s = s + 0.015625f * w.v[2][2];
+    o[0] = s;
+    s = 0.0f; s = s + 0.0625f * w.v[0][1]; s = s + 0.0625f * w.v[0][2]; s = s + 0.375f * w.v[1][1];
+    s = s + 0.375f * w.v[1][2]; s = s + 0.0625f * w.v[2][1]; s = s + 0.0625f * w.v[2][2];
+    o[1] = s;
+    s = 0.0f; s = s + 0.0625f * w.v[1][0]; s = s + 0.375f * w.v[1][1]; s = s + 0.0625f * w.v[1][2];
+    s = s + 0.0625f * w.v[2][0]; s = s + 0.375f * w.v[2][1]; s = s + 0.0625f * w.v[2][2];
+    o[2] = s;
+    s = 0.0f; s = s + 0.25f * w.v[1][1]; s = s + 0.25f * w.v[1][2]; s = s + 0.25f * w.v[2][1]; s = s + 0.25f * w.v[2][2];
+    o[3] = s;
+}
+DEVI void filt_base_br(const Win3& w, float o[4]) {  // base position BOTTOM_RIGHT (blue)
+    float s;
+    s = 0.0f; s = s + 0.25f * w.v[0][0]; s = s + 0.25f * w.v[0][1]; s = s + 0.25f * w.v[1][0]; s = s + 0.25f * w.v[1][1];
+    o[0] = s;
+    s = 0.0f; s = s + 0.0625f * w.v[0][0]; s = s + 0.375f * w.v[0][1]; s = s + 0.0625f * w.v[0][2];
+    s = s + 0.0625f * w.v[1][0]; s = s + 0.375f * w.v[1][1]; s = s + 0.0625f * w.v[1][2];
+    o[1] = s;
+    s = 0.0f; s = s + 0.0625f * w.v[0][0]; s = s + 0.0625f * w.v[0][1]; s = s + 0.375f * w.v[1][0];
+    s = s + 0.375f * w.v[1][1]; s = s + 0.0625f * w.v[2][0]; s = s + 0.0625f * w.v[2][1];
+    o[2] = s;
+    s = 0.0f; s = s + 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; s = s + 0.015625f * w.v[0][2];
+    s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
+    s = s + 0.015625f * w.v[2][0]; s = s + 0.09375f * w.v[2][1]; s = s + 0.015625f * w.v[2][2];
+    o[3] = s;
+}
+
+// g - GaussianBlur3(g) on the 4x4 full-resolution window around a quad (ahd.py:120-121)
+DEVI void highpass_quad(const float W[4][4], float hf[4]) {
+    float rb[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) rb[r][k] = W[r][k + 1] * GK0 + (W[r][k] + W[r][k + 2]) * GK1;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            float bl = rb[rr + 1][k] * GK0 + (rb[rr][k] + rb[rr + 2][k]) * GK1;
+            hf[rr * 2 + k] = W[rr + 1][k + 1] - bl;
+        }
+}
+

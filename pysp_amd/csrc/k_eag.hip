@@ -1,0 +1,182 @@
+// k_eag.hip -- Edge-Assisted-Gaussian ("Fast") and Draft demosaic for gfx950.
+//
+// EAG follows debayer/edge_assisted_gaussian.py:10-201 of pySP; Draft follows
+// debayer/fast_resize.py:7-44 (+ cv2.resize INTER_LINEAR x2 restated as in oracle/pysp_oracle.c).
+//
+// EAG kernel: one workgroup = one 64x32 px output tile = 32x16 CFA quads, one thread per quad.
+//   P0  raw mosaic -> four de-interleaved quarter planes in LDS (halo 2 quads, symmetric border)
+//   P1  gradient-weighted green at R/B sites * wb[1], colour differences D = sub*wb - g
+//       (halo 1 quad; outside the image: REFLECT_101 of the quarter plane)
+//   P2  per quad: g - GaussianBlur3(g), photosite-aware resampling of R and B, colour tail, store
+#include "demosaic_common.h"
+#include "kernels.h"
+
+namespace {
+constexpr int TQX = 32, TQY = 16;
+constexpr int MWX = TQX + 4, MWY = TQY + 4;   // raw planes, halo 2 quads
+constexpr int GX = TQX + 2, GY = TQY + 2;     // green / difference planes, halo 1 quad
+constexpr int NT = TQX * TQY;                 // 512
+enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
+enum { Q_GR = 0, Q_GB, Q_DR, Q_DB };
+
+// edge_assisted_gaussian.py:36-49
+DEVI float delta_mix(float top, float bottom, float left, float right) {
+    float dy = fabsf(top - bottom), dx = fabsf(left - right), s = dy + dx;
+    float ax = (left + right) / 2.0f, ay = (top + bottom) / 2.0f;
+    float sy = s != 0.0f ? dy / s : 0.5f;
+    float sx = 1.0f - sy;
+    return ay * sx + ax * sy;
+}
+}  // namespace
+
+struct EagParams {
+    const float* bayer;
+    float* out;
+    int H, W;
+    float wb[3];
+    int tail;
+    Ccm ccm;
+};
+
+__global__ void __launch_bounds__(NT) k_eag(EagParams p) {
+    __shared__ float mw[4][MWY][MWX];
+    __shared__ float gq[4][GY][GX];
+    const int tid = threadIdx.x;
+    const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
+    const int tq0x = blockIdx.x * TQX, tq0y = blockIdx.y * TQY;
+
+    // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87)
+    for (int idx = tid; idx < 4 * MWY * MWX; idx += NT) {
+        int ry = idx / (2 * MWX), rx = idx - ry * (2 * MWX);
+        int my = ry >> 1, mx = rx >> 1, dy = ry & 1, dx = rx & 1;
+        int qi = b_sym(tq0y - 2 + my, h), qj = b_sym(tq0x - 2 + mx, w);
+        int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
+        mw[plane][my][mx] = p.bayer[(size_t)(2 * qi + dy) * W + (2 * qj + dx)];
+    }
+    __syncthreads();
+
+    // P1: green at red / blue sites (eag.py:99-121), * wb[1] (:193); D = sub*wb - g (:142,:194)
+    for (int idx = tid; idx < GY * GX; idx += NT) {
+        int gy = idx / GX, gx = idx - gy * GX;
+        int ri = b_101(tq0y - 1 + gy, h), rj = b_101(tq0x - 1 + gx, w);
+        int a = ri - (tq0y - 2), c = rj - (tq0x - 2);
+        if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;
+        float gr = delta_mix(mw[P_G2][a - 1][c], mw[P_G2][a][c], mw[P_G1][a][c - 1], mw[P_G1][a][c]) * p.wb[1];
+        float gb = delta_mix(mw[P_G1][a][c], mw[P_G1][a + 1][c], mw[P_G2][a][c], mw[P_G2][a][c + 1]) * p.wb[1];
+        gq[Q_GR][gy][gx] = gr; gq[Q_GB][gy][gx] = gb;
+        gq[Q_DR][gy][gx] = mw[P_R][a][c] * p.wb[0] - gr;
+        gq[Q_DB][gy][gx] = mw[P_B][a][c] * p.wb[2] - gb;
+    }
+    __syncthreads();
+
+    // P2
+    const int lqy = tid / TQX, lqx = tid - lqy * TQX;
+    const int qi = tq0y + lqy, qj = tq0x + lqx;
+    if (qi >= h || qj >= w) return;
+    const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
+    const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
+    const float wg = p.wb[1];
+    Win3 wgr = load_win<GX>(&gq[Q_GR][0][0], gy, gx), wgb = load_win<GX>(&gq[Q_GB][0][0], gy, gx);
+    float g1_c = mw[P_G1][my][mx] * wg, g2_c = mw[P_G2][my][mx] * wg;
+    float Wn[4][4] = {{wgb.v[0][0], mw[P_G2][my - 1][mx] * wg, wgb.v[0][1], mw[P_G2][my - 1][mx + 1] * wg},
+                      {mw[P_G1][my][mx - 1] * wg, wgr.v[1][1], g1_c, wgr.v[1][2]},
+                      {wgb.v[1][0], g2_c, wgb.v[1][1], mw[P_G2][my][mx + 1] * wg},
+                      {mw[P_G1][my + 1][mx - 1] * wg, wgr.v[2][1], mw[P_G1][my + 1][mx] * wg, wgr.v[2][2]}};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {     // GaussianBlur REFLECT_101 at full resolution
+        if (at_top) Wn[0][k] = Wn[2][k];
+        if (at_bot) Wn[3][k] = Wn[1][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (at_left) Wn[k][0] = Wn[k][2];
+        if (at_right) Wn[k][3] = Wn[k][1];
+    }
+    float hf[4], fg[4], fd[4], rr[4], bb[4];
+    highpass_quad(Wn, hf);                                           // eag.py:156
+    filt_base_tl(wgr, fg);
+    { Win3 wd = load_win<GX>(&gq[Q_DR][0][0], gy, gx); filt_base_tl(wd, fd); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) rr[k] = fd[k] + (fg[k] + hf[k]);     // eag.py:141,143
+    filt_base_br(wgb, fg);
+    { Win3 wd = load_win<GX>(&gq[Q_DB][0][0], gy, gx); filt_base_br(wd, fd); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) bb[k] = fd[k] + (fg[k] + hf[k]);
+    float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float r = rr[k], g = gg[k], b = bb[k];
+        colour_tail(p.tail, p.ccm.m, r, g, b);
+        float* o = p.out + ((size_t)(2 * qi + (k >> 1)) * W + (2 * qj + (k & 1))) * 3;
+        o[0] = r; o[1] = g; o[2] = b;
+    }
+}
+
+int launch_eag(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
+    EagParams a;
+    a.bayer = d_bayer; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
+    for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
+    for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
+    dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
+    if (tl) tl->begin(st, "k_eag");
+    hipLaunchKernelGGL(k_eag, g, dim3(NT), 0, st, a);
+    if (tl) tl->end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ================================================================================================
+// Draft (fast_resize.py:21-39): quarter-resolution RGB with 3/4-1/4 diagonal R/B alignment, then
+// bilinear x2 (half-pixel centres, edge clamp; horizontal pass then vertical pass).
+namespace {
+DEVI void draft_q(const float* __restrict__ bay, int h, int w, int W, int i, int j, const float wb[3], float q[3]) {
+    int i1 = i + 1 < h ? i + 1 : h - 1, j1 = j + 1 < w ? j + 1 : w - 1;   // r padded bottom/right (REFLECT)
+    int i0 = i > 0 ? i - 1 : 0, j0 = j > 0 ? j - 1 : 0;                   // b padded top/left
+    float r = bay[(size_t)(2 * i) * W + 2 * j], rd = bay[(size_t)(2 * i1) * W + 2 * j1];
+    float b = bay[(size_t)(2 * i + 1) * W + 2 * j + 1], bd = bay[(size_t)(2 * i0 + 1) * W + 2 * j0 + 1];
+    float g1 = bay[(size_t)(2 * i) * W + 2 * j + 1], g2 = bay[(size_t)(2 * i + 1) * W + 2 * j];
+    q[0] = (0.75f * r + 0.25f * rd) * wb[0];
+    q[1] = ((g1 + g2) / 2.0f) * wb[1];
+    q[2] = (0.75f * b + 0.25f * bd) * wb[2];
+}
+DEVI void lin_tap(int X, int n, int& s0, int& s1, float& a0, float& a1) {
+    float f = ((float)X + 0.5f) * 0.5f - 0.5f;
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.0f; }
+    if (s >= n - 1) { s = n - 1; f = 0.0f; }
+    s0 = s; s1 = s + 1 < n ? s + 1 : s; a0 = 1.0f - f; a1 = f;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_draft(EagParams p) {
+    int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
+    if (X >= W) return;
+    int sx0, sx1, sy0, sy1; float a0, a1, b0, b1;
+    lin_tap(X, w, sx0, sx1, a0, a1);
+    lin_tap(Y, h, sy0, sy1, b0, b1);
+    float q00[3], q01[3], q10[3], q11[3];
+    draft_q(p.bayer, h, w, W, sy0, sx0, p.wb, q00); draft_q(p.bayer, h, w, W, sy0, sx1, p.wb, q01);
+    draft_q(p.bayer, h, w, W, sy1, sx0, p.wb, q10); draft_q(p.bayer, h, w, W, sy1, sx1, p.wb, q11);
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float h0 = q00[c] * a0 + q01[c] * a1, h1 = q10[c] * a0 + q11[c] * a1;
+        o[c] = h0 * b0 + h1 * b1;
+    }
+    colour_tail(p.tail, p.ccm.m, o[0], o[1], o[2]);
+    float* d = p.out + ((size_t)Y * W + X) * 3;
+    d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+}
+
+int launch_draft(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
+    EagParams a;
+    a.bayer = d_bayer; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
+    for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
+    for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
+    dim3 g((W + 255) / 256, H);
+    if (tl) tl->begin(st, "k_draft");
+    hipLaunchKernelGGL(k_draft, g, dim3(256), 0, st, a);
+    if (tl) tl->end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,211 @@
+// k_misc.hip -- HDR raw fusion (raw_hdr.py:85-158) and DNG WarpRectilinear
+// (dng_warp_corr/dng_warp_rectilinear_coords.pyx + chan_distortion_corr.py:86-97) for gfx950.
+#include <math.h>
+
+#include "devmath.h"
+#include "kernels.h"
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -3)
+
+// ---- HDR raw fusion -------------------------------------------------------------------------------
+// Pointwise over K exposures: VEC px per thread per frame (float4 when W % 4 == 0, else float2: W is
+// even, so every row start stays 8-byte aligned and column parity is known at compile time).
+namespace { constexpr int MAXK = 16; }
+struct FuseParams {
+    const float* frames[MAXK];
+    float ev_off[MAXK];
+    float bias[MAXK][4];   // CFA site order r,g1,b,g2
+    int K, kmax, H, W;
+    float* out;
+    int32_t* count;
+};
+template <int VEC>
+__global__ void __launch_bounds__(256) k_fuse_raw(FuseParams p) {
+    int xq = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (xq * VEC >= p.W) return;
+    // site index of (even, odd) columns in this row: even row -> r(0), g1(1); odd row -> g2(3), b(2)
+    const int odd = y & 1, c_even = odd ? 3 : 0, c_odd = odd ? 2 : 1;
+    size_t o = (size_t)y * p.W + (size_t)VEC * xq;
+    float sw[VEC], sp[VEC], v[VEC];
+    int cnt[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; t++) { sw[t] = 0.0f; sp[t] = 0.0f; cnt[t] = 0; }
+    for (int k = 0; k < p.K; k++) {
+        if (VEC == 4) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(p.frames[k] + o);
+        else *reinterpret_cast<float2*>(v) = *reinterpret_cast<const float2*>(p.frames[k] + o);
+        const float off = p.ev_off[k];
+#pragma unroll
+        for (int t = 0; t < VEC; t++) {
+            float wgt = (0.5f - fabsf(v[t] - 0.5f)) * p.bias[k][(t & 1) ? c_odd : c_even];   // raw_hdr.py:137
+            sw[t] = sw[t] + wgt;                                                            // :138
+            sp[t] = sp[t] + (v[t] * wgt) * off;                                             // :139
+            cnt[t] += wgt > 0.0f ? 1 : 0;                                                   // :141
+        }
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(p.frames[p.kmax] + o);
+    else *reinterpret_cast<float2*>(v) = *reinterpret_cast<const float2*>(p.frames[p.kmax] + o);
+    const float mo = p.ev_off[p.kmax];
+    float res[VEC];
+#pragma unroll
+    for (int t = 0; t < VEC; t++) res[t] = sw[t] == 0.0f ? v[t] * mo : sp[t] / sw[t];       // :144-148
+    if (VEC == 4) {
+        *reinterpret_cast<float4*>(p.out + o) = *reinterpret_cast<float4*>(res);
+        *reinterpret_cast<int4*>(p.count + o) = *reinterpret_cast<int4*>(cnt);
+    } else {
+        *reinterpret_cast<float2*>(p.out + o) = *reinterpret_cast<float2*>(res);
+        *reinterpret_cast<int2*>(p.count + o) = *reinterpret_cast<int2*>(cnt);
+    }
+}
+int launch_fuse_raw(hipStream_t st, const float* const* d_frames, int K, int H, int W, const float* ev_off, const float* bias,
+                    int kmax, float* d_out, int32_t* d_count) {
+    if (K < 1 || K > MAXK || (W & 1)) return -1;
+    FuseParams p;
+    uintptr_t align = reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_count);
+    for (int k = 0; k < K; k++) {
+        p.frames[k] = d_frames[k];
+        p.ev_off[k] = ev_off[k];
+        for (int c = 0; c < 4; c++) p.bias[k][c] = bias[k * 4 + c];
+        align |= reinterpret_cast<uintptr_t>(d_frames[k]);
+    }
+    if (align & 15) return -1;
+    p.K = K; p.kmax = kmax; p.H = H; p.W = W; p.out = d_out; p.count = d_count;
+    if ((W & 3) == 0) {
+        dim3 g((W / 4 + 255) / 256, H);
+        hipLaunchKernelGGL(k_fuse_raw<4>, g, dim3(256), 0, st, p);
+    } else {
+        dim3 g((W / 2 + 255) / 256, H);
+        hipLaunchKernelGGL(k_fuse_raw<2>, g, dim3(256), 0, st, p);
+    }
+    return CHECK_LAUNCH();
+}
+
+// ---- WarpRectilinear ------------------------------------------------------------------------------
+// pyx:18-40.  Cython lowers x**k on C floats to powf(x, k.0) (correctly rounded to float32 by glibc
+// in all but ~0.3 % of arguments) and sqrt to the double sqrt.  Here x**2 is the exact float32
+// product, x**4 / x**6 are float64 products rounded once, sqrt is the float64 sqrt.
+struct WarpGeom { float cx, cy, m; };
+static WarpGeom warp_geom(int width, int height, float cxn, float cyn) {
+    WarpGeom g;
+    g.cx = (float)(width - 1) * cxn;
+    g.cy = (float)(height - 1) * cyn;
+    float mx = fmaxf(fabsf(-g.cx), fabsf((float)(width - 1) - g.cx));
+    float my = fmaxf(fabsf(-g.cy), fabsf((float)(height - 1) - g.cy));
+    g.m = (float)sqrt((double)(mx * mx + my * my));
+    return g;
+}
+struct WarpCoef { float kr0, kr1, kr2, kr3, kt0, kt1; };
+DEVI void warp_px(float sx, float sy, const WarpCoef& k, const WarpGeom& g, float scale, float& ox, float& oy) {
+    float dx = (sx - g.cx) / g.m, dy = (sy - g.cy) / g.m;
+    float dx2 = dx * dx, dy2 = dy * dy;
+    float r = (float)sqrt((double)(dx2 + dy2));
+    double rd = (double)r, r2d = rd * rd;
+    float r2 = (float)r2d, r4 = (float)(r2d * r2d), r6 = (float)((r2d * r2d) * r2d);
+    float f = ((k.kr0 + (k.kr1 * r2)) + (k.kr2 * r4)) + (k.kr3 * r6);
+    float dxr = f * dx, dyr = f * dy;
+    float dxt = k.kt0 * ((2.0f * dx) * dy) + k.kt1 * (r2 + 2.0f * dx2);
+    float dyt = k.kt1 * ((2.0f * dx) * dy) + k.kt0 * (r2 + 2.0f * dy2);
+    float xp = g.cx + g.m * (dxr + dxt), yp = g.cy + g.m * (dyr + dyt);
+    ox = sx + (xp - sx) * scale;
+    oy = sy + (yp - sy) * scale;
+}
+__global__ void __launch_bounds__(256) k_warp_table(WarpCoef k, WarpGeom g, float scale, int width, int height,
+                                                    const float* __restrict__ seed, float* __restrict__ table) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    size_t o = ((size_t)y * width + x) * 2;
+    float sx = seed ? seed[o] : (float)x, sy = seed ? seed[o + 1] : (float)y;
+    float ox, oy;
+    warp_px(sx, sy, k, g, scale, ox, oy);
+    *reinterpret_cast<float2*>(table + o) = make_float2(ox, oy);
+}
+int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
+                      float cxn, float cyn, float scale, const float* d_seed, float* d_table) {
+    WarpCoef k = {kr0, kr1, kr2, kr3, kt0, kt1};
+    WarpGeom g = warp_geom(width, height, cxn, cyn);
+    dim3 grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(k_warp_table, grid, dim3(256), 0, st, k, g, scale, width, height, d_seed, d_table);
+    return CHECK_LAUNCH();
+}
+
+// Restated cv2.remap(INTER_LANCZOS4, BORDER_CONSTANT 0), oracle orc_remap_lanczos4: the coordinate
+// table is evaluated in the kernel (never materialised), clipped (chan_distortion_corr.py:95-96),
+// quantised to 1/32 px (round half even), 8x8 taps with weights wy*wx, row sums then total.
+void host_lanczos4_table(float tab[256]) {
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    for (int i = 0; i < 32; i++) {
+        float x = (float)i * (1.0f / 32.0f);
+        float* c = tab + 8 * i;
+        if (x < 1.1920929e-07f) { for (int k = 0; k < 8; k++) c[k] = 0; c[3] = 1; continue; }
+        float sum = 0;
+        double y0 = -(x + 3) * 3.14159265358979323846 * 0.25, s0 = sin(y0), c0 = cos(y0);
+        for (int k = 0; k < 8; k++) {
+            double y = -(x + 3 - k) * 3.14159265358979323846 * 0.25;
+            c[k] = (float)((cs[k][0] * s0 + cs[k][1] * c0) / (y * y));
+            sum += c[k];
+        }
+        sum = 1.f / sum;
+        for (int k = 0; k < 8; k++) c[k] *= sum;
+    }
+}
+struct RemapParams {
+    const float* in;   // (H,W,3)
+    float* out;        // (H,W,3), must not alias in
+    const float* tab;  // [32][8]
+    int H, W;
+    WarpCoef k[3];
+    WarpGeom g;
+    float scale;
+};
+__global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
+    __shared__ float stab[256];
+    stab[threadIdx.x] = p.tab[threadIdx.x];
+    __syncthreads();
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W || y >= p.H) return;
+    const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
+    float res[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float mx, my;
+        warp_px((float)x, (float)y, p.k[c], p.g, p.scale, mx, my);
+        mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);
+        my = my < 0.0f ? 0.0f : (my > ymax ? ymax : my);
+        int sx = (int)rintf(mx * 32.0f), sy = (int)rintf(my * 32.0f);
+        int ix = (sx >> 5) - 3, iy = (sy >> 5) - 3;
+        const float* wx = stab + 8 * (sx & 31);
+        const float* wy = stab + 8 * (sy & 31);
+        float sum = 0.0f;
+        for (int r = 0; r < 8; r++) {
+            int yy = iy + r;
+            bool yin = (unsigned)yy < (unsigned)p.H;
+            const float* row = p.in + ((size_t)(yin ? yy : 0) * p.W) * 3 + c;
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                int xx = ix + t;
+                float s = (yin && (unsigned)xx < (unsigned)p.W) ? row[(size_t)xx * 3] : 0.0f;
+                float v = s * (wy[r] * wx[t]);
+                acc = t == 0 ? v : acc + v;
+            }
+            sum = sum + acc;
+        }
+        res[c] = sum;
+    }
+    float* o = p.out + ((size_t)y * p.W + x) * 3;
+    o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+}
+int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
+                      double cyn, float scale, const float* d_lanczos_tab) {
+    if (planes != 3) return -1;
+    RemapParams p;
+    p.in = d_in; p.out = d_out; p.tab = d_lanczos_tab; p.H = H; p.W = W; p.scale = scale;
+    for (int c = 0; c < 3; c++) {
+        const double* k = coeffs + 6 * c;
+        p.k[c] = {(float)k[0], (float)k[1], (float)k[2], (float)k[3], (float)k[4], (float)k[5]};
+    }
+    p.g = warp_geom(W, H, (float)cxn, (float)cyn);
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_warp_remap, grid, dim3(256), 0, st, p);
+    return CHECK_LAUNCH();
+}

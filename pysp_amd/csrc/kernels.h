@@ -1,0 +1,46 @@
+// kernels.h -- host-side launchers of the gfx950 kernels (one translation unit per family).
+// All launchers enqueue on `st` and return 0 or PYSP_EHIP (-3); pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// Optional per-kernel timing: when `on`, every launcher brackets each kernel it enqueues with events.
+struct Timeline {
+    static constexpr int MAXK = 8;
+    hipEvent_t ev[2 * MAXK];
+    const char* name[MAXK];
+    int n = 0;
+    bool on = false;
+    void begin(hipStream_t st, const char* nm) { if (on && n < MAXK) { name[n] = nm; (void)hipEventRecord(ev[2 * n], st); } }
+    void end(hipStream_t st) { if (on && n < MAXK) { (void)hipEventRecord(ev[2 * n + 1], st); n++; } }
+};
+
+// k_basic.hip
+int launch_demux_f32(hipStream_t st, const float* bayer, int H, int W, float* r, float* g1, float* b, float* g2);
+int launch_demux_u16(hipStream_t st, const uint16_t* bayer, int H, int W, float* r, float* g1, float* b, float* g2);
+int launch_remux_f32(hipStream_t st, const float* r, const float* g1, const float* b, const float* g2, int h, int w, float* bayer);
+int launch_normalize_u16(hipStream_t st, const uint16_t* bayer, int H, int W, const float black[4], const float sat[4], float* out);
+int launch_build_map(hipStream_t st, const float* lab, int Hp, int Wp, int k_pad, int is_vertical, float* out);
+int launch_cam_to_rgb(hipStream_t st, const float* in, size_t npx, const double M[9], int clip, float* out);
+int launch_gamma(hipStream_t st, const float* in, size_t n, int decode, float* out);
+int launch_wb_scale(hipStream_t st, const float* in, size_t npx, const float coeff[3], int undo, float* out);
+int launch_colour_tail(hipStream_t st, const float* in, size_t npx, const double M[9], int tail, float* out);
+
+// k_ahd.hip: tail = colour tail of devmath.h (0 none, 1 lin sRGB, 2 sRGB, 3 Reinhard + sRGB);
+// d_tmp0/d_tmp1 are (H,W,3) scratch images (only needed when stages >= 1 / >= 2).
+int launch_ahd(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
+               int tail, float* d_out, float* d_tmp0, float* d_tmp1, Timeline* tl = nullptr);
+
+// k_eag.hip
+int launch_eag(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
+int launch_draft(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
+
+// k_misc.hip
+int launch_fuse_raw(hipStream_t st, const float* const* d_frames_host_array, int K, int H, int W, const float* ev_off,
+                    const float* bias, int kmax, float* d_out, int32_t* d_count);
+int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
+                      float cxn, float cyn, float scale, const float* d_seed, float* d_table);
+int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
+                      double cyn, float scale, const float* d_lanczos_tab);
+void host_lanczos4_table(float tab[256]);

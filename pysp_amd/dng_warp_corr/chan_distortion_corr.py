@@ -1,0 +1,63 @@
+"""DNG OpcodeList3 WarpRectilinear on the GPU (reference dng_warp_corr/chan_distortion_corr.py:11-121).
+
+The per-plane coordinate table is evaluated inside the remap kernel and never materialised
+(814 MB per plane at 100 MP).  Reading the opcode blob out of a DNG (`get_opcode_3_block`,
+tifftools) is file I/O and stays outside this package.
+"""
+from __future__ import annotations
+
+import ctypes
+from struct import unpack
+from typing import Optional
+
+import numpy as np
+
+from .. import _lib
+
+
+def stack_warp_prior(demosaiced_image: np.ndarray, remap_r: Optional[np.ndarray], remap_g: Optional[np.ndarray],
+                     remap_b: Optional[np.ndarray]) -> np.ndarray:
+    """(H, W, 3, 2) prior from per-channel cv2.remap style maps; missing channels get the identity."""
+    if remap_r is None or remap_g is None or remap_b is None:
+        h, w = demosaiced_image.shape[:2]
+        ident = np.empty((h, w, 2), np.float32)
+        ident[..., 0] = np.arange(w, dtype=np.float32)[None, :]
+        ident[..., 1] = np.arange(h, dtype=np.float32)[:, None]
+        remap_r = ident if remap_r is None else remap_r
+        remap_g = ident if remap_g is None else remap_g
+        remap_b = ident if remap_b is None else remap_b
+    return np.stack((remap_r, remap_g, remap_b), axis=2)
+
+
+def _warp_rectilinear(image: np.ndarray, data: bytes, scale: float, prior) -> bool:
+    if len(data) < 4:
+        return False
+    planes = int.from_bytes(data[:4], byteorder="big")
+    if len(data) != 4 + 48 * planes + 16 or planes != image.shape[2]:
+        return False
+    coeffs = np.array([unpack(">6d", data[4 + 48 * p: 4 + 48 * (p + 1)]) for p in range(planes)], dtype=np.float64)
+    cx, cy = unpack(">2d", data[4 + 48 * planes: 4 + 48 * planes + 16])
+    if prior is not None:
+        raise NotImplementedError("seeded (prior) warps are evaluated with compute_offset_remapping_table; "
+                                  "the fused in-place path takes no prior yet")
+    if image.dtype != np.float32 or not image.flags.c_contiguous:
+        raise ValueError("apply_opcode_3_warp works in place on a C-contiguous float32 (H, W, 3) image")
+    H, W, _ = image.shape
+    _lib.check(_lib.lib().pysp_warp_rectilinear_f32(_lib.default_context().handle, _lib.ptr(image), H, W,
+                                                    coeffs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), planes, cx, cy, scale))
+    return True
+
+
+def apply_opcode_3_warp(demosaiced_image: np.ndarray, ifd_opcode_3_data: bytes, scale: float = 1.0, prior: Optional[np.ndarray] = None):
+    """Apply every WarpRectilinear (opcode 1) of an OpcodeList3 blob in place, in order; others are skipped."""
+    assert prior is None or prior.shape == demosaiced_image.shape + (2,)
+    count = int.from_bytes(ifd_opcode_3_data[:4], byteorder="big")
+    offset = 4
+    for _ in range(count):
+        opcode_id, _ver, _flags, var_len = unpack(">4I", ifd_opcode_3_data[offset:offset + 16])
+        offset += 16
+        if opcode_id == 1:
+            _warp_rectilinear(demosaiced_image, ifd_opcode_3_data[offset:offset + var_len], scale, prior)
+        else:
+            print("Unimplemented opcode %d" % opcode_id)
+        offset += var_len

@@ -1,0 +1,23 @@
+"""Sensor-range normalisation on the GPU (reference normalization.py:4-24)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def bayer_normalize(rgbg: np.ndarray, chan_black, chan_sat) -> np.ndarray:
+    """clip(x - black_c, 0, sat_c) / sat_c per CFA site (r, g1, b, g2), float32 throughout.
+
+    The reference receives Python-int lists from rawpy, so the arithmetic is float32; NumPy integer
+    scalars would silently promote its result to float64 -- here they are treated like the lists.
+    """
+    if rgbg.dtype != np.uint16:
+        raise ValueError("bayer_normalize expects the uint16 mosaic delivered by the raw decoder")
+    src = np.ascontiguousarray(rgbg)
+    H, W = src.shape
+    black = (ctypes.c_float * 4)(*[float(chan_black[i]) for i in range(4)])
+    sat = (ctypes.c_float * 4)(*[float(chan_sat[i]) for i in range(4)])
+    out = np.empty((H, W), np.float32)
+    _lib.check(_lib.lib().pysp_bayer_normalize_u16(_lib.default_context().handle, _lib.ptr(src), H, W, black, sat, _lib.ptr(out)))
+    return out

@@ -1,0 +1,299 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (pysp_amd -> libpysp_hip.so), against
+  (1) the golden fixtures produced by the reference's own code, and
+  (2) the CPU oracle on the same seeded inputs.
+Bars: bit-exact for Bayer indexing, votes, selection, medians and every float32 stage whose
+operations are +,-,*,/ (the kernels are built with -ffp-contract=off and evaluate in the oracle's
+order); <= 1 ULP for the two stages that go through a float64 pow (sRGB curves); stated tolerance
+for WarpRectilinear, whose reference arithmetic calls libm powf.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import D65_XY, MULT, XYZ2CAM, load_golden, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wbobj():
+    from pysp_amd.synth import default_wb
+    return default_wb()
+
+
+def _raw(bayer, wbobj, hdr=False, ev=10.0):
+    from pysp_amd.image import RawRggbBayerData
+    im = RawRggbBayerData(bayer, wbobj, ev, 1.0)
+    im.set_hdr(hdr)
+    return im
+
+
+def _wbM(orc):
+    return (1.0 / MULT).astype(np.float32), orc.final_matrix(XYZ2CAM, orc.xy_to_XYZ(D65_XY))
+
+
+# ---- Bayer helpers ---------------------------------------------------------------------------------
+def test_demux_remux_normalize_golden():
+    from pysp_amd.bayer_chan_mixer import bayer_to_rgbg, rgbg_to_bayer
+    from pysp_amd.normalization import bayer_normalize
+    d, _ = load_golden("g1_demux")
+    for src in ("f32", "u16"):
+        for p, k in zip(bayer_to_rgbg(d[src]), ("r", "g1", "b", "g2")):
+            assert p.dtype == np.float32 and np.array_equal(p, d[f"{src}_{k}"])
+    assert np.array_equal(rgbg_to_bayer(*bayer_to_rgbg(d["f32"])), d["remux"])
+    g, _ = load_golden("g6_normalize")
+    assert np.array_equal(bayer_normalize(g["raw"], g["black"].tolist(), g["sat"].tolist()), g["out"])
+
+
+def test_demux_remux_large_roundtrip():
+    from pysp_amd.bayer_chan_mixer import bayer_to_rgbg, rgbg_to_bayer
+    a = np.random.default_rng(0).random((1026, 2050), dtype=np.float32)
+    planes = bayer_to_rgbg(a)
+    assert np.array_equal(planes[0], a[0::2, 0::2]) and np.array_equal(planes[2], a[1::2, 1::2])
+    assert np.array_equal(rgbg_to_bayer(*planes), a)
+    with pytest.raises(ValueError):
+        bayer_to_rgbg(a[:-1])
+
+
+# ---- homogeneity vote --------------------------------------------------------------------------------
+def test_build_map_golden_and_oracle(orc):
+    from pysp_amd.debayer import build_map
+    d, _ = load_golden("g3_build_map")
+    for name in ("lab", "labq"):
+        assert np.array_equal(build_map(d[name], 1, 3, False), d[name + "_h"])
+        assert np.array_equal(build_map(d[name], 1, 3, True), d[name + "_v"])
+    rng = np.random.default_rng(5)
+    lab = (rng.random((203, 331, 3)) * 40).astype(np.float32)
+    lab[50:90, 100:200] = np.round(lab[50:90, 100:200])       # many exact ties
+    for v in (False, True):
+        assert np.array_equal(build_map(lab, 1, 3, v), orc.build_map(lab, 1, v))
+    assert np.array_equal(build_map(np.ones((9, 9, 3), np.float32), 1, 3, False), np.full((7, 7), 9, np.float32))
+    with pytest.raises(ValueError):
+        build_map(lab.astype(np.float64), 1, 3, False)
+
+
+# ---- colour ---------------------------------------------------------------------------------------------
+def test_cam_to_lin_srgb_golden():
+    from pysp_amd.colorize.transform import cam_to_lin_srgb
+    from pysp_amd.wb_cct.helpers_cam_mat import MatXyzToCamera
+    d, _ = load_golden("g4_cam_to_rgb")
+    for i in range(3):
+        mat = MatXyzToCamera(d[f"m{i}"], d[f"white{i}"])
+        assert np.array_equal(cam_to_lin_srgb(d["px"], mat, True), d[f"out{i}_clip"])
+        assert np.array_equal(cam_to_lin_srgb(d["px"], mat, False), d[f"out{i}_noclip"])
+
+
+def test_gamma(orc):
+    from pysp_amd.colorize import lin_srgb_to_srgb, srgb_to_lin_srgb
+    d, _ = load_golden("g5_gamma")
+    enc = lin_srgb_to_srgb(d["x"])
+    # vs the correctly rounded oracle: float64 pow on both sides -> identical but for double-rounding ties
+    u = ulp_diff(enc, orc.lin_srgb_to_srgb(d["x"]))
+    assert u.max() <= 1 and np.mean(u != 0) < 1e-4
+    # vs NumPy's float32 power on the fixture box (platform-dependent last bit, amplified <= 4 ULP at the toe)
+    assert ulp_diff(enc, d["enc"]).max() <= 4
+    dec = srgb_to_lin_srgb(d["x"])
+    u = ulp_diff(dec, orc.srgb_to_lin_srgb(d["x"]))
+    assert u.max() <= 1 and np.mean(u != 0) < 1e-4
+    assert ulp_diff(dec, d["dec"]).max() <= 1
+    x = np.random.default_rng(1).random((257, 129, 3), dtype=np.float32) * 1.2 - 0.1
+    assert ulp_diff(lin_srgb_to_srgb(x), orc.lin_srgb_to_srgb(x)).max() <= 1
+
+
+# ---- demosaic: fixtures from the reference orchestration -----------------------------------------------------
+@pytest.mark.parametrize("name", ["g8_demosaic_32x48", "g8_demosaic_34x50", "g8_demosaic_32x48_hdr", "g8_demosaic_34x50_hdr"])
+def test_demosaic_golden(name, wbobj):
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.const import QualityDemosaic
+    d, meta = load_golden(name)
+    hdr = meta["hdr"]
+    if not hdr:
+        assert np.array_equal(_raw(d["bayer"], wbobj).demosaic(QualityDemosaic.Draft).image, d["draft"])
+        assert np.array_equal(_raw(d["bayer"], wbobj).demosaic(QualityDemosaic.Fast).image, d["eag"])
+    for st in (0, 1, 3):
+        dem = _raw(d["bayer"], wbobj, hdr).demosaic(QualityDemosaic.Best, st)
+        assert dem.image.dtype == np.float32 and np.array_equal(dem.image, d[f"ahd{st}"]), st
+        if st == 1:
+            lin = dem.to_lin_srgb()
+            assert np.array_equal(lin, d["ahd1_lin"])
+            srgb = lin_srgb_to_srgb(lin / (1 + lin) if hdr else lin)
+            assert ulp_diff(srgb, d["ahd1_srgb"]).max() <= 4
+
+
+def test_cfa_patterns_golden(wbobj):
+    from pysp_amd.base_types.image_base import BayerPattern
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawBayerData
+    d, _ = load_golden("g8_cfa_patterns")
+    for pat in BayerPattern:
+        rb = RawBayerData()
+        rb.sensor_scaled = d["bayer"]; rb.cam_wb = wbobj; rb.current_ev = 9.0; rb.sensor_pattern = pat
+        out = rb.demosaic(QualityDemosaic.Fast)
+        assert np.array_equal(out.image, d[f"eag_{pat.name}"]), pat
+        assert out.current_ev == 9.0 and out.mat_xyz is not None
+
+
+def test_unknown_quality_raises(wbobj):
+    with pytest.raises(NotImplementedError):
+        _raw(np.zeros((4, 4), np.float32), wbobj).demosaic("best")
+    from pysp_amd import _lib
+    import ctypes
+    rc = _lib.lib().pysp_demosaic_f32(_lib.default_context().handle, None, 4, 4, _lib.wb3([1, 1, 1]), None, 7, 0, 0, None)
+    assert rc == _lib.PYSP_EBADARG
+    a = np.zeros((4, 4), np.float32); o = np.zeros((4, 4, 3), np.float32)
+    rc = _lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(a), 4, 4, _lib.wb3([1, 1, 1]), None, 7, 0, 0, _lib.ptr(o))
+    assert rc == _lib.PYSP_ENOTIMPL and "not implemented" in _lib.last_error()
+    rc = _lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(a), 3, 4, _lib.wb3([1, 1, 1]), None, 0, 0, 0, _lib.ptr(o))
+    assert rc == _lib.PYSP_EBADARG
+
+
+# ---- demosaic vs the oracle on seeded inputs: ragged sizes, tile seams, tiny frames, worst-case noise -------------
+SIZES = [(2, 2), (2, 4), (4, 2), (4, 6), (6, 134), (70, 2), (62, 66), (64, 128), (66, 130), (130, 198), (256, 320)]
+
+
+@pytest.mark.parametrize("H,W", SIZES)
+def test_demosaic_vs_oracle_sizes(orc, wbobj, H, W):
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.synth import random_frame, rggb_frame
+    wb, M = _wbM(orc)
+    for bay in (rggb_frame(H, W, 1000 + H + W), random_frame(H, W, H * W)):
+        assert np.array_equal(_raw(bay, wbobj).demosaic(QualityDemosaic.Draft).image, orc.demosaic_draft(bay, wb))
+        assert np.array_equal(_raw(bay, wbobj).demosaic(QualityDemosaic.Fast).image, orc.demosaic_eag(bay, wb))
+        for st in (0, 1, 2):
+            got = _raw(bay, wbobj).demosaic(QualityDemosaic.Best, st).image
+            assert np.array_equal(got, orc.demosaic_ahd(bay, wb, M, False, st)), (H, W, st)
+
+
+@pytest.mark.parametrize("H,W", [(66, 130), (200, 264)])
+def test_demosaic_hdr_vs_oracle(orc, wbobj, H, W):
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    bay = rggb_frame(H, W, 77, scale=4.0, clip_hi=False)
+    for st in (0, 1, 3):
+        got = _raw(bay, wbobj, hdr=True).demosaic(QualityDemosaic.Best, st).image
+        assert np.array_equal(got, orc.demosaic_ahd(bay, wb, M, True, st))
+
+
+def test_ahd_medium_frame_and_fused_pipeline(orc, wbobj):
+    """1.5 MP frame: staged API (3 materialising calls) and the fused single-call pipeline both match."""
+    from pysp_amd import _lib
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.synth import rggb_frame
+    H, W = 1000, 1500
+    bay = rggb_frame(H, W, 1001)
+    wb, M = _wbM(orc)
+    ref_rgb = orc.demosaic_ahd(bay, wb, M, False, 1)
+    dem = _raw(bay, wbobj).demosaic(QualityDemosaic.Best, 1)
+    assert np.array_equal(dem.image, ref_rgb)
+    lin = dem.to_lin_srgb()
+    assert np.array_equal(lin, orc.cam_to_rgb(ref_rgb, M, True))
+    ref_srgb = orc.pipeline_srgb(bay, wb, M, 2, False, 1, False)
+    u = ulp_diff(lin_srgb_to_srgb(lin), ref_srgb)
+    assert u.max() <= 1 and np.mean(u != 0) < 1e-4
+    fused = np.empty((H, W, 3), np.float32)
+    for q, orc_q in ((_lib.QUALITY_BEST, 2), (_lib.QUALITY_FAST, 1), (_lib.QUALITY_DRAFT, 0)):
+        _lib.check(_lib.lib().pysp_pipeline_srgb_f32(_lib.default_context().handle, _lib.ptr(bay), H, W, _lib.wb3(wb), _lib.mat9(M), q, 0, 1, 0,
+                                                    _lib.ptr(fused)))
+        u = ulp_diff(fused, orc.pipeline_srgb(bay, wb, M, orc_q, False, 1, False))
+        assert u.max() <= 1 and np.mean(u != 0) < 1e-4, q
+
+
+# ---- size-independent properties at the benchmark's full size (24 MP) ---------------------------------------------
+def test_full_size_24mp_properties(orc, wbobj):
+    from pysp_amd import _lib
+    from pysp_amd.synth import rggb_frame
+    H, W = 4000, 6000
+    bay = rggb_frame(H, W, 1000)
+    wb, M = _wbM(orc)
+    full = np.empty((H, W, 3), np.float32)
+    L, ctx = _lib.lib(), _lib.default_context()
+    _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 0, 1, 0, _lib.ptr(full)))
+    assert np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
+    # (a) tile/translation invariance: a crop with >= 16 px margin reproduces the interior of the full frame,
+    #     wherever it falls relative to the 64x32 tile grid (offsets are even so the CFA phase is kept)
+    for (y0, x0, h, w) in ((0, 0, 300, 420), (1234, 2022, 310, 402), (H - 300, W - 420, 300, 420), (2000, 0, 260, 300)):
+        crop = np.ascontiguousarray(bay[y0:y0 + h, x0:x0 + w])
+        out = np.empty((h, w, 3), np.float32)
+        _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(crop), h, w, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 0, 1, 0, _lib.ptr(out)))
+        ys = slice(0 if y0 == 0 else 16, h if y0 + h == H else h - 16)
+        xs = slice(0 if x0 == 0 else 16, w if x0 + w == W else w - 16)
+        assert np.array_equal(out[ys, xs], full[y0:y0 + h, x0:x0 + w][ys, xs]), (y0, x0)
+        # (b) the same crop against the oracle, bit for bit up to the pow stage
+        u = ulp_diff(out, orc.pipeline_srgb(crop, wb, M, 2, False, 1, False))
+        assert u.max() <= 1 and np.mean(u != 0) < 1e-4
+    # (c) a constant mosaic in camera-neutral proportions comes out as one constant grey
+    flat = np.empty((128, 192), np.float32)
+    flat[0::2, 0::2] = 0.2 * 0.5; flat[0::2, 1::2] = 0.2; flat[1::2, 0::2] = 0.2; flat[1::2, 1::2] = 0.2 * 0.7
+    out = np.empty((128, 192, 3), np.float32)
+    _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(flat), 128, 192, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 0, 1, 0, _lib.ptr(out)))
+    assert np.ptp(out) < 1e-6
+
+
+# ---- HDR raw fusion ---------------------------------------------------------------------------------------------------
+def test_fuse_raw_golden_and_oracle(orc, wbobj):
+    from pysp_amd.raw_hdr import fuse_exposures_to_raw
+    from pysp_amd.synth import rggb_frame
+    d, meta = load_golden("g9_fuse_raw")
+    exps = [_raw(f, wbobj, ev=ev) for f, ev in zip(d["frames"], meta["evs"])]
+    hdr, cnt = fuse_exposures_to_raw(exps)
+    assert np.array_equal(hdr.sensor_scaled, d["fused"]) and np.array_equal(cnt, d["count"]) and cnt.dtype == np.int32
+    assert hdr.get_hdr() and hdr.current_ev == meta["target_ev"] and hdr.lim_sat == meta["lim_sat"]
+    assert fuse_exposures_to_raw([]) is None
+    # 7 exposures, ragged width (W % 4 == 2), against the oracle
+    H, W, K = 130, 202, 7
+    base = rggb_frame(H, W, 5, scale=6.0, clip_hi=False)
+    evs = [10.0 + k for k in range(K)]
+    frames = [np.clip(base * np.float32(2.0 ** -k), 0, 1).astype(np.float32) for k in range(K)]
+    frames[0][:8, :8] = 1.0
+    for f in frames[1:]:
+        f[:4, :4] = 1.0
+    hdr, cnt = fuse_exposures_to_raw([_raw(f, wbobj, ev=e) for f, e in zip(frames, evs)])
+    ref, refc, target, lim = orc.fuse_raw(frames, evs, 1.0 / MULT)
+    assert np.array_equal(hdr.sensor_scaled, ref) and np.array_equal(cnt, refc)
+    assert hdr.current_ev == target and hdr.lim_sat == lim
+
+
+# ---- WarpRectilinear ------------------------------------------------------------------------------------------------------
+def test_warp_table(orc):
+    """The reference evaluates r**4 and r**6 with libm powf (not always correctly rounded); the kernel
+    uses exactly rounded products, so single coordinates may differ in the last bit."""
+    from pysp_amd.dng_warp_corr import compute_offset_remapping_table, compute_remapping_table
+    d, meta = load_golden("g7_warp_table")
+    a = meta["args"]
+    t = compute_remapping_table(a["kr0"], a["kr1"], a["kr2"], a["kr3"], a["kt0"], a["kt1"], a["width"], a["height"], a["cx"], a["cy"], a["scale"])
+    assert t.shape == d["table"].shape and ulp_diff(t, d["table"]).max() <= 2
+    s = meta["seeded_args"]
+    t1 = compute_offset_remapping_table(d["table"], s[0], s[1], s[2], s[3], s[4], s[5], a["width"], a["height"], s[6], s[7], s[8])
+    assert ulp_diff(t1, d["seeded"]).max() <= 2
+    big = compute_remapping_table(1.0, 0.01, 0.002, 0.0, 0.0, 0.0, 1201, 801, 0.5, 0.5, 1.0)
+    ref = orc.warp_table(1.0, 0.01, 0.002, 0.0, 0.0, 0.0, 1201, 801, 0.5, 0.5, 1.0)
+    u = ulp_diff(big, ref)
+    assert u.max() <= 2 and np.mean(u != 0) < 0.02
+
+
+def test_warp_apply(orc):
+    from pysp_amd.dng_warp_corr import apply_opcode_3_warp
+    d, _ = load_golden("g10_warp_apply")
+    img = d["image"].copy()
+    apply_opcode_3_warp(img, d["blob"].tobytes())
+    diff = np.abs(img - d["warped"])
+    # a coordinate that differs in its last bit can cross a 1/32 px quantisation boundary: rare, small
+    assert np.mean(diff > 0) < 2e-3 and diff.max() < 2e-2
+    rng = np.random.default_rng(3)
+    big = rng.random((301, 402, 3), dtype=np.float32)
+    coeffs = np.array([[1.0, 0.01, 0.002, 0.0, 0.0, 0.0], [1.0, -0.01, 0.002, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0, 0.001, -0.001]])
+    import struct
+    payload = struct.pack(">I", 3) + b"".join(struct.pack(">6d", *c) for c in coeffs) + struct.pack(">2d", 0.5, 0.5)
+    blob = struct.pack(">I", 1) + struct.pack(">IIII", 1, 1, 0, len(payload)) + payload
+    got = big.copy()
+    apply_opcode_3_warp(got, blob)
+    ref = orc.warp_rectilinear(big, coeffs, (0.5, 0.5))
+    diff = np.abs(got - ref)
+    assert np.mean(diff > 0) < 2e-3 and diff.max() < 5e-2
+    ident = big.copy()      # kr0 = 1, everything else 0 -> identity mapping -> exact copy
+    payload = struct.pack(">I", 3) + struct.pack(">6d", 1, 0, 0, 0, 0, 0) * 3 + struct.pack(">2d", 0.5, 0.5)
+    apply_opcode_3_warp(ident, struct.pack(">I", 1) + struct.pack(">IIII", 1, 1, 0, len(payload)) + payload)
+    assert np.mean(ident != big) < 1e-3
