@@ -40,12 +40,26 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
 
 
+def threads() -> int:
+    """OpenMP team size used by the oracle: OMP_NUM_THREADS if set, else min(available cores, 16)."""
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        return max(1, int(os.environ["OMP_NUM_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
         build()
+        # A container may see every host core through os.cpu_count() while its CPU quota is far smaller;
+        # an OpenMP team sized for the host then crawls.  Cap the team unless the caller chose a size.
         name = "liboracle_fma.so" if _cpu_has_fma() else "liboracle.so"
         _LIB = ctypes.CDLL(os.path.join(_HERE, name))
+        _LIB.orc_set_threads(threads())
     return _LIB
 
 

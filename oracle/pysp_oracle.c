@@ -911,4 +911,10 @@ int orc_warp_rectilinear(float *image, int H, int W, const double *coeffs, int p
     return ORC_OK;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int orc_set_threads(int n) { (void)n; return 1; }
+#endif
 int orc_abi_version(void) { return 1; }
