@@ -71,17 +71,16 @@ def main() -> None:
     H, W, quality, stages, desc = WORKLOADS[args.workload]
     mp_per_frame = H * W / 1e6
 
-    # ---- shared parameters: rank 0 owns them, everyone receives them over RCCL/xGMI
-    params = torch.zeros(12, dtype=torch.float64, device=dev)
+    # ---- shared parameters: rank 0 owns them, everyone receives them over RCCL/xGMI (once per batch)
+    from pysp_amd.multi_gpu import broadcast_params
     if rank == 0:
         wbobj = default_wb()
-        params[:3] = torch.from_numpy(wbobj.get_reciprocal_multipliers().astype(np.float64))
-        params[3:] = torch.from_numpy(final_matrix(wbobj.get_matrix()).reshape(-1))
-    if dist is not None:
-        dist.broadcast(params, src=0)
-    p = params.cpu().numpy()
-    wb = _lib.wb3(p[:3].astype(np.float32))
-    M = _lib.mat9(p[3:])
+        wb_np, M_np = broadcast_params(wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix()), src=0, device=dev)
+    else:
+        wb_np, M_np = broadcast_params(np.zeros(3, np.float32), np.zeros((3, 3)), src=0, device=dev)
+    p = np.concatenate([wb_np.astype(np.float64), M_np.reshape(-1)])
+    wb = _lib.wb3(wb_np)
+    M = _lib.mat9(M_np)
 
     # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
     frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
