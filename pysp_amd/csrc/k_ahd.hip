@@ -4,7 +4,7 @@
 // Follows debayer/ahd.py:14-170 and debayer/ahd_homogeneity_cython.pyx:22-58 of pySP, with the
 // OpenCV calls restated as in oracle/pysp_oracle.c (same op order, bit for bit).
 //
-// Kernel A works on 2x2 CFA quads.  One workgroup = one 64x32 px output tile (32x16 quads):
+// Kernel A works on 2x2 CFA quads.  One workgroup = one 28x28 px output tile (14x14 quads, 16x16 threads):
 //   P0  mosaic * wb -> four de-interleaved quarter planes in LDS (halo 3 quads, symmetric border)
 //   P1  green at red/blue sites, horizontal and vertical, and the colour differences D = sub - g
 //       (halo 2 quads; positions outside the image hold the REFLECT_101 value the 3x3 plane
@@ -21,13 +21,17 @@
 
 namespace {
 
-constexpr int TQX = 32, TQY = 16;                 // output quads per tile
+#ifndef AHD_TQX
+#define AHD_TQX 14                                // measured on MI355X: 256-thread workgroups (3 per CU at ~165 VGPRs)
+#define AHD_TQY 14                                // beat 384/512/640-thread ones by 1.3-1.9x despite the larger halo share
+#endif
+constexpr int TQX = AHD_TQX, TQY = AHD_TQY;       // output quads per tile; the 1-quad halo makes (TQX+2)x(TQY+2) threads
 constexpr int MWX = TQX + 6, MWY = TQY + 6;       // mosaic planes, halo 3 quads
 constexpr int GX = TQX + 4, GY = TQY + 4;         // green / difference planes, halo 2 quads
 constexpr int LQX = TQX + 2, LQY = TQY + 2;       // Lab region in quads (halo 1 quad = 2 px)
 constexpr int LPS = 2 * LQX + 2, LPR = 2 * LQY + 2;  // Lab plane stride / rows: region + 1 px guard ring (70 x 38)
 constexpr int MPS = 2 * TQX + 4, MPR = 2 * TQY + 2;  // packed vote map (halo 1 px), stride 68 (8-byte aligned rows)
-constexpr int NT_A = 640;                         // >= LQX*LQY = 612
+constexpr int NT_A = LQX * LQY;                    // 512: one thread per quad of the halo-1 region
 #ifndef AHD_MIN_WAVES
 #define AHD_MIN_WAVES 1                           // measured: forcing 5 waves/SIMD (96 VGPRs) spills 51 dwords and is 45 % slower
 #endif
@@ -74,6 +78,38 @@ DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool a
     }
 }
 
+// pyx:22-58 for the four pixels of a quad.  DIR 0: epsilons from the left/right neighbours (map_h),
+// DIR 1: from the up/down neighbours (map_v).  The centre and the two epsilon neighbours always count:
+// x - c <= max(|c - x|, .) and the chroma distance of a neighbour is one of the two maximised squares
+// (d*d == (-d)*(-d) bit for bit), so only the other six window cells are tested.
+template <int DIR>
+DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
+        float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
+        float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
+        float da1 = ra - wa[n1y][n1x], db1 = rb - wq[n1y][n1x], da2 = ra - wa[n2y][n2x], db2 = rb - wq[n2y][n2x];
+        float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
+        float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
+        int c = 3;
+#pragma unroll
+        for (int wy = 0; wy < 3; wy++)
+#pragma unroll
+            for (int wx = 0; wx < 3; wx++) {
+                const int y = dy + wy, x = dx + wx;
+                if ((y == cy && x == cx) || (y == n1y && x == n1x) || (y == n2y && x == n2x)) continue;
+                float da = wa[y][x] - ra, db = wq[y][x] - rb;
+                bool ok = (wl[y][x] - rl <= el) && (da * da + db * db <= ec);
+                c += ok ? 1 : 0;
+            }
+        cnt[k] = c;
+    }
+}
+
+static_assert(12 * TQX * TQY <= 4 * MWY * MWX + 4 * GY * GX, "rgb_h stash must fit in the dead planes");
+
 }  // namespace
 
 struct AhdParams {
@@ -89,8 +125,12 @@ struct AhdParams {
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
 template <bool TINY>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
-    __shared__ float mw[4 * MWY * MWX];               // 13.4 KB
-    __shared__ float gq[8 * GY * GX];                 // 23.0 KB
+    // planes: mosaic (dead after P1), then green/difference planes direction-major (direction 0 dead after its
+    // P2).  The front of this array is reused for the horizontal RGB candidates while the vertical pass runs.
+    __shared__ __attribute__((aligned(16))) float planes[4 * MWY * MWX + 8 * GY * GX];
+    float* const mw = planes;
+    float* const gq = planes + 4 * MWY * MWX;
+    float* const rgbh_lds = planes;                  // [12][TQY*TQX], needs 12*420 floats <= 4*MWY*MWX + 4*GY*GX
     __shared__ __attribute__((aligned(16))) float lab[3 * LPR * LPS];   // 31.9 KB, one direction at a time
     __shared__ __attribute__((aligned(16))) unsigned short vmap[MPR * MPS];   // 4.6 KB, votes: h | v << 8
 
@@ -133,13 +173,15 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 
     const int lqy = tid / LQX, lqx = tid - lqy * LQX;
     const int qi = tq0y - 1 + lqy, qj = tq0x - 1 + lqx;
-    const bool active = tid < LQX * LQY && qi >= 0 && qi < h && qj >= 0 && qj < w;
+    const bool active = qi >= 0 && qi < h && qj >= 0 && qj < w;
     const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
     const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
     // vote-map cell of this quad's top-left pixel (map origin = tile origin - 1 px)
     const int vmy = 2 * lqy - 1, vmx = 2 * lqx - 1;
 
-    float rgbh[4][3], rgbv[4][3];
+    float rgbv[4][3];
+    const bool inner = active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX;
+    const int oq = (lqy - 1) * TQX + (lqx - 1);      // index of this quad among the tile's output quads
     float g1_l = 0, g1_c = 0, g1_dl = 0, g1_d = 0, g2_u = 0, g2_ur = 0, g2_c = 0, g2_r = 0;
     if (active) {   // green samples of the 4x4 window, shared by both directions
         g1_l = MWAT(P_G1, my, mx - 1); g1_c = MWAT(P_G1, my, mx); g1_dl = MWAT(P_G1, my + 1, mx - 1); g1_d = MWAT(P_G1, my + 1, mx);
@@ -148,7 +190,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 
 #pragma unroll 1
     for (int dir = 0; dir < 2; dir++) {
-        float labq[4][3];
+        float labq[4][3], rgbc[4][3];
         // ---- P2
         if (active) {
             const float* gR = gq + (4 * dir + 0) * GY * GX;
@@ -187,8 +229,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 homog_lab(rr[k], gg[k], bb[k], p.wb, M, p.hdr, labq[k][0], labq[k][1], labq[k][2]);
-                if (dir == 0) { rgbh[k][0] = rr[k]; rgbh[k][1] = gg[k]; rgbh[k][2] = bb[k]; }
-                else          { rgbv[k][0] = rr[k]; rgbv[k][1] = gg[k]; rgbv[k][2] = bb[k]; }
+                rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
+                __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
             }
         }
         if (dir == 1) __syncthreads();   // votes of direction 0 are done reading the Lab buffer
@@ -202,6 +244,20 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             }
         }
         __syncthreads();
+        // every thread is past P2 of this direction: the mosaic planes and this direction's g/D planes are dead
+        if (dir == 0) {
+            if (inner) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) rgbh_lds[(k * 3 + c) * (TQX * TQY) + oq] = rgbc[k][c];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) rgbv[k][c] = rgbc[k][c];
+        }
 
         // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 window
         if (active) {
@@ -209,32 +265,15 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             load_lab_win(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_win(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+            int cnt[4];
+            if (dir == 0) vote_quad<0>(wl, wa, wq, cnt); else vote_quad<1>(wl, wa, wq, cnt);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
-                float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
-                // neighbours: left/right for the horizontal map, up/down for the vertical one
-                float n1l = dir ? wl[cy - 1][cx] : wl[cy][cx - 1], n2l = dir ? wl[cy + 1][cx] : wl[cy][cx + 1];
-                float n1a = dir ? wa[cy - 1][cx] : wa[cy][cx - 1], n2a = dir ? wa[cy + 1][cx] : wa[cy][cx + 1];
-                float n1b = dir ? wq[cy - 1][cx] : wq[cy][cx - 1], n2b = dir ? wq[cy + 1][cx] : wq[cy][cx + 1];
-                float e1 = fabsf(rl - n1l), e2 = fabsf(rl - n2l);
-                float da1 = ra - n1a, db1 = rb - n1b, da2 = ra - n2a, db2 = rb - n2b;
-                float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
-                float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
-                int cnt = 0;
-#pragma unroll
-                for (int wy = 0; wy < 3; wy++)
-#pragma unroll
-                    for (int wx = 0; wx < 3; wx++) {
-                        float da = wa[dy + wy][dx + wx] - ra, db = wq[dy + wy][dx + wx] - rb;
-                        bool ok = (wl[dy + wy][dx + wx] - rl <= el) && (da * da + db * db <= ec);
-                        cnt += ok ? 1 : 0;
-                    }
-                int yy = vmy + dy, xx = vmx + dx;
+                int yy = vmy + (k >> 1), xx = vmx + (k & 1);
                 if (yy >= 0 && yy < MPR && xx >= 0 && xx < 2 * TQX + 2) {
                     unsigned short* cell = &vmap[yy * MPS + xx];
-                    if (dir == 0) *cell = (unsigned short)cnt;
-                    else *cell = (unsigned short)(*cell | (cnt << 8));
+                    if (dir == 0) *cell = (unsigned short)cnt[k];
+                    else *cell = (unsigned short)(*cell | (cnt[k] << 8));
                 }
             }
         }
@@ -243,7 +282,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     __syncthreads();
 
     // ---- P4: 3x3 box (cv2.blur, REFLECT_101; integer sums order like the float means), select, store
-    if (active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX) {
+    if (inner) {
         // 4x4 packed votes around the quad: rows vmy-1..vmy+2, cols vmx-1..vmx+2 (vmx-1 is even)
         unsigned int s012[4], s123[4];
 #pragma unroll
@@ -263,9 +302,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             unsigned int s = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
             unsigned int sh = s & 0xFFu, sv = s >> 8;
             float c = sh < sv ? 1.0f : 0.0f, nc = 1.0f - c;            // ahd.py:139-145, literally
-            float r = rgbh[k][0] * c + rgbv[k][0] * nc;
-            float g = rgbh[k][1] * c + rgbv[k][1] * nc;
-            float b = rgbh[k][2] * c + rgbv[k][2] * nc;
+            float r = rgbh_lds[(k * 3 + 0) * (TQX * TQY) + oq] * c + rgbv[k][0] * nc;
+            float g = rgbh_lds[(k * 3 + 1) * (TQX * TQY) + oq] * c + rgbv[k][1] * nc;
+            float b = rgbh_lds[(k * 3 + 2) * (TQX * TQY) + oq] * c + rgbv[k][2] * nc;
             colour_tail(p.tail, M, r, g, b);
             float* o = p.out + ((size_t)(2 * qi + dy) * W + (2 * qj + dx)) * 3;
             o[0] = r; o[1] = g; o[2] = b;
@@ -278,23 +317,29 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 //   r' = med5(r-g)+g ; b' = med5(b-g)+g ; g' = (med5(g-r') + med5(g-b') + r' + b') / 2
 // cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.  Tile 64x32 px, halo 4 px.
 namespace {
-constexpr int BTX = 64, BTY = 32;
+constexpr int BTX = 32, BTY = 32;
 constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // r-g, b-g planes (halo 4)
 constexpr int B2X = BTX + 4, B2Y = BTY + 4;     // g-r', g-b' planes (halo 2)
-constexpr int NT_B = 512;
+constexpr int NT_B = 256;
 
 // Median of 25 by a selection network (exact; order independent).  It is the classic 99-exchange
 // network; wherever three exchanges (b,c),(a,c),(a,b) fully sort a triple they are issued as one
 // v_min3 / v_med3 / v_max3 group (3 VALU ops instead of 6).  Exhaustive 0-1 check: tools/check_median25.c.
-#define CE(a, b) { float _t = fminf(v[a], v[b]); v[b] = fmaxf(v[a], v[b]); v[a] = _t; }
-#define S3(a, b, c) { float _lo = fminf(fminf(v[a], v[b]), v[c]); float _hi = fmaxf(fmaxf(v[a], v[b]), v[c]); \
-                      float _md = __builtin_amdgcn_fmed3f(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
-DEVI float median25(float v[25]) {
+// Two independent windows are pushed through the network in lockstep: the network is one long
+// dependency chain, and the second window fills its issue bubbles.
+#define CE1(v, a, b) { float _t = fminf(v[a], v[b]); v[b] = fmaxf(v[a], v[b]); v[a] = _t; }
+#define S31(v, a, b, c) { float _lo = fminf(fminf(v[a], v[b]), v[c]); float _hi = fmaxf(fmaxf(v[a], v[b]), v[c]); \
+                          float _md = __builtin_amdgcn_fmed3f(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
+#define CE(a, b) { CE1(v, a, b) CE1(u, a, b) }
+#define S3(a, b, c) { S31(v, a, b, c) S31(u, a, b, c) }
+DEVI void median25x2(float v[25], float u[25], float& mv, float& mu) {
 #include "median25_network.inc"
-    return v[12];
+    mv = v[12]; mu = u[12];
 }
 #undef CE
 #undef S3
+#undef CE1
+#undef S31
 }  // namespace
 
 struct MedParams {
@@ -324,36 +369,31 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
     for (int idx = tid; idx < B2Y * B2X; idx += NT_B) {
         int oy = idx / B2X, ox = idx - oy * B2X;
         int ly = b_rep(ty0 - 2 + oy, H) - (ty0 - 2), lx = b_rep(tx0 - 2 + ox, W) - (tx0 - 2);
-        float v[25];
+        float v[25], u[25];
 #pragma unroll
         for (int dy = 0; dy < 5; dy++)
 #pragma unroll
-            for (int dx = 0; dx < 5; dx++) v[dy * 5 + dx] = s_drg[ly + dy][lx + dx];
-        float g = s_g[ly + 2][lx + 2];
-        float r1 = median25(v) + g;
-#pragma unroll
-        for (int dy = 0; dy < 5; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 5; dx++) v[dy * 5 + dx] = s_dbg[ly + dy][lx + dx];
-        float b1 = median25(v) + g;
-        s_r1[oy][ox] = r1; s_b1[oy][ox] = b1;
+            for (int dx = 0; dx < 5; dx++) { v[dy * 5 + dx] = s_drg[ly + dy][lx + dx]; u[dy * 5 + dx] = s_dbg[ly + dy][lx + dx]; }
+        float g = s_g[ly + 2][lx + 2], mr, mb;
+        median25x2(v, u, mr, mb);
+        s_r1[oy][ox] = mr + g; s_b1[oy][ox] = mb + g;
     }
     __syncthreads();
     for (int idx = tid; idx < BTY * BTX; idx += NT_B) {
         int ly = idx / BTX, lx = idx - ly * BTX;
         int y = ty0 + ly, x = tx0 + lx;
         if (y >= H || x >= W) continue;
-        float v[25];
+        float v[25], u[25];
 #pragma unroll
         for (int dy = 0; dy < 5; dy++)
 #pragma unroll
-            for (int dx = 0; dx < 5; dx++) v[dy * 5 + dx] = s_g[ly + 2 + dy][lx + 2 + dx] - s_r1[ly + dy][lx + dx];
-        float m1 = median25(v);
-#pragma unroll
-        for (int dy = 0; dy < 5; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 5; dx++) v[dy * 5 + dx] = s_g[ly + 2 + dy][lx + 2 + dx] - s_b1[ly + dy][lx + dx];
-        float m2 = median25(v);
+            for (int dx = 0; dx < 5; dx++) {
+                float g = s_g[ly + 2 + dy][lx + 2 + dx];
+                v[dy * 5 + dx] = g - s_r1[ly + dy][lx + dx];
+                u[dy * 5 + dx] = g - s_b1[ly + dy][lx + dx];
+            }
+        float m1, m2;
+        median25x2(v, u, m1, m2);
         float r = s_r1[ly + 2][lx + 2], b = s_b1[ly + 2][lx + 2];
         float g = (((m1 + m2) + r) + b) / 2.0f;
         colour_tail(p.tail, p.ccm.m, r, g, b);
