@@ -350,9 +350,23 @@ struct MedParams {
     Ccm ccm;
 };
 
+// Window of a horizontally adjacent pixel pair: 5 rows x 6 columns starting at an even column -> three
+// 8-byte LDS reads per row.  v = window of the left pixel, u = window of the right pixel.
+DEVI void load_pair_windows(const float* plane, int stride, int ly, int lx, float v[25], float u[25]) {
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) {
+        const float2* row = reinterpret_cast<const float2*>(plane + (ly + dy) * stride + lx);
+        float2 a = row[0], b = row[1], c = row[2];
+        float w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
+#pragma unroll
+        for (int dx = 0; dx < 5; dx++) { v[dy * 5 + dx] = w[dx]; u[dy * 5 + dx] = w[dx + 1]; }
+    }
+}
+
 __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
-    __shared__ float s_g[B4Y][B4X], s_drg[B4Y][B4X], s_dbg[B4Y][B4X];   // g, r-g, b-g   (halo 4)
-    __shared__ float s_r1[B2Y][B2X], s_b1[B2Y][B2X];                     // r', b'        (halo 2)
+    __shared__ __attribute__((aligned(16))) float s_g[B4Y][B4X], s_drg[B4Y][B4X], s_dbg[B4Y][B4X];   // g, r-g, b-g (halo 4)
+    __shared__ __attribute__((aligned(16))) float s_r1[B2Y][B2X], s_b1[B2Y][B2X];                     // r', b'      (halo 2)
+    __shared__ __attribute__((aligned(16))) float s_d1[B2Y][B2X], s_d2[B2Y][B2X];                     // g-r', g-b'  (halo 2)
     const int tid = threadIdx.x, H = p.H, W = p.W;
     const int tx0 = blockIdx.x * BTX, ty0 = blockIdx.y * BTY;
 
@@ -364,41 +378,59 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         s_g[ly][lx] = g; s_drg[ly][lx] = r - g; s_dbg[ly][lx] = b - g;
     }
     __syncthreads();
-    // r', b' on the halo-2 region.  medianBlur replicates the border of ITS input plane, so r', b' at a
-    // position outside the image are those of the clamped position: evaluate the window there.
-    for (int idx = tid; idx < B2Y * B2X; idx += NT_B) {
-        int oy = idx / B2X, ox = idx - oy * B2X;
-        int ly = b_rep(ty0 - 2 + oy, H) - (ty0 - 2), lx = b_rep(tx0 - 2 + ox, W) - (tx0 - 2);
-        float v[25], u[25];
-#pragma unroll
-        for (int dy = 0; dy < 5; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 5; dx++) { v[dy * 5 + dx] = s_drg[ly + dy][lx + dx]; u[dy * 5 + dx] = s_dbg[ly + dy][lx + dx]; }
-        float g = s_g[ly + 2][lx + 2], mr, mb;
-        median25x2(v, u, mr, mb);
-        s_r1[oy][ox] = mr + g; s_b1[oy][ox] = mb + g;
+    // r', b' and the second-level differences on the halo-2 region, two horizontally adjacent pixels per
+    // thread (W and the tile origin are even, so a pair is inside or outside the image as a whole).
+    for (int idx = tid; idx < B2Y * (B2X / 2); idx += NT_B) {
+        int oy = idx / (B2X / 2), ox = 2 * (idx - oy * (B2X / 2));
+        int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
+        if (y < 0 || y >= H || x < 0 || x >= W) continue;       // filled from the clamped position below
+        float v[25], u[25], m0, m1;
+        load_pair_windows(&s_drg[0][0], B4X, oy, ox, v, u);
+        median25x2(v, u, m0, m1);
+        float g0 = s_g[oy + 2][ox + 2], g1 = s_g[oy + 2][ox + 3];
+        float r0 = m0 + g0, r1 = m1 + g1;
+        load_pair_windows(&s_dbg[0][0], B4X, oy, ox, v, u);
+        median25x2(v, u, m0, m1);
+        float b0 = m0 + g0, b1 = m1 + g1;
+        *reinterpret_cast<float2*>(&s_r1[oy][ox]) = make_float2(r0, r1);
+        *reinterpret_cast<float2*>(&s_b1[oy][ox]) = make_float2(b0, b1);
+        *reinterpret_cast<float2*>(&s_d1[oy][ox]) = make_float2(g0 - r0, g1 - r1);
+        *reinterpret_cast<float2*>(&s_d2[oy][ox]) = make_float2(g0 - b0, g1 - b1);
     }
     __syncthreads();
-    for (int idx = tid; idx < BTY * BTX; idx += NT_B) {
-        int ly = idx / BTX, lx = idx - ly * BTX;
+    // medianBlur replicates the border of ITS input plane: a position outside the image takes the values of
+    // the clamped position (only tiles touching the image border have any).
+    if (ty0 < 2 || tx0 < 2 || ty0 + BTY + 2 > H || tx0 + BTX + 2 > W) {
+        for (int idx = tid; idx < B2Y * B2X; idx += NT_B) {
+            int oy = idx / B2X, ox = idx - oy * B2X;
+            int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
+            if (y >= 0 && y < H && x >= 0 && x < W) continue;
+            int cy = b_rep(y, H) - (ty0 - 2), cx = b_rep(x, W) - (tx0 - 2);
+            if (cy < 0 || cy >= B2Y || cx < 0 || cx >= B2X) continue;     // beyond a partial tile: never consumed
+            s_d1[oy][ox] = s_d1[cy][cx]; s_d2[oy][ox] = s_d2[cy][cx];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < BTY * (BTX / 2); idx += NT_B) {
+        int ly = idx / (BTX / 2), lx = 2 * (idx - ly * (BTX / 2));
         int y = ty0 + ly, x = tx0 + lx;
         if (y >= H || x >= W) continue;
-        float v[25], u[25];
-#pragma unroll
-        for (int dy = 0; dy < 5; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 5; dx++) {
-                float g = s_g[ly + 2 + dy][lx + 2 + dx];
-                v[dy * 5 + dx] = g - s_r1[ly + dy][lx + dx];
-                u[dy * 5 + dx] = g - s_b1[ly + dy][lx + dx];
-            }
-        float m1, m2;
-        median25x2(v, u, m1, m2);
-        float r = s_r1[ly + 2][lx + 2], b = s_b1[ly + 2][lx + 2];
-        float g = (((m1 + m2) + r) + b) / 2.0f;
-        colour_tail(p.tail, p.ccm.m, r, g, b);
+        float v[25], u[25], ma0, ma1, mb0, mb1;
+        load_pair_windows(&s_d1[0][0], B2X, ly, lx, v, u);
+        median25x2(v, u, ma0, ma1);
+        load_pair_windows(&s_d2[0][0], B2X, ly, lx, v, u);
+        median25x2(v, u, mb0, mb1);
+        float2 rr = *reinterpret_cast<const float2*>(&s_r1[ly + 2][lx + 2]);
+        float2 bb = *reinterpret_cast<const float2*>(&s_b1[ly + 2][lx + 2]);
+        float r0 = rr.x, b0 = bb.x, r1 = rr.y, b1 = bb.y;
+        float g0 = (((ma0 + mb0) + r0) + b0) / 2.0f, g1 = (((ma1 + mb1) + r1) + b1) / 2.0f;
+        colour_tail(p.tail, p.ccm.m, r0, g0, b0);
+        colour_tail(p.tail, p.ccm.m, r1, g1, b1);
         float* o = p.out + ((size_t)y * W + x) * 3;
-        o[0] = r; o[1] = g; o[2] = b;
+        // six contiguous floats, 8-byte aligned (x is even)
+        reinterpret_cast<float2*>(o)[0] = make_float2(r0, g0);
+        reinterpret_cast<float2*>(o)[1] = make_float2(b0, r1);
+        reinterpret_cast<float2*>(o)[2] = make_float2(g1, b1);
     }
 }
 
