@@ -33,7 +33,10 @@ DEVI int b_1011(int p, int n) {
     return r < 0 ? 0 : (r >= n ? n - 1 : r);
 }
 
-DEVI float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }  // transform.py:6-19
+// np.clip(x, 0, 1) (transform.py:6-19) as one v_med3_f32: on gfx950 compares/selects/min/max/med3 issue at half
+// the rate of f32 add/mul/fma (4 vs 2 cycles per wave, tools/ubench_valu2.hip), so one med3 replaces four slow ops.
+// Identical to the compare form for every non-NaN input up to the sign of a zero result.
+DEVI float clip01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
 
 // ---- 3x3 colour matrix, transform.py:52-53: float64 accumulate in dgemm order, one rounding ----
 struct Ccm { double m[9]; };
@@ -71,11 +74,11 @@ DEVI float lab_decode(float v) {
     // both sides are evaluated (no divergence); the pow argument is clamped into its domain so the
     // unused lane value stays finite
     float u = (v + 0.055f) * 0.9478673f;
-    float p = lab_pow24(u < 0.09f ? 0.09f : u);
+    float p = lab_pow24(fmaxf(u, 0.09f));
     return v <= 0.04045f ? v * 0.07739938f : p;
 }
 DEVI float lab_f(float t) {
-    float c = lab_cbrt(t < 0.008f ? 0.008f : t);
+    float c = lab_cbrt(fmaxf(t, 0.008f));
     return t > 0.008856f ? c : __builtin_fmaf(7.787f, t, 0.13793103f);
 }
 DEVI void rgb2lab_px(float R, float G, float B, float& L, float& a, float& b) {
@@ -113,7 +116,7 @@ DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
 }
 DEVI float srgb_encode(float x) {
     x = clip01(x);
-    float p = srgb_pow_5_12(x < 0.003f ? 0.003f : x);
+    float p = srgb_pow_5_12(fmaxf(x, 0.003f));
     return x <= 0.0031308f ? x * 12.92f : 1.055f * p - 0.055f;
 }
 DEVI float srgb_decode(float x) {

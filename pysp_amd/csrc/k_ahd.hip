@@ -66,15 +66,17 @@ DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool a
         float2 b = *reinterpret_cast<const float2*>(p + r * LPS + 2);
         w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
     }
+    if (at_top | at_bot | at_left | at_right) {   // interior waves skip the 16 selects
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        if (at_top) w[0][c] = w[1][c];
-        if (at_bot) w[3][c] = w[2][c];
-    }
+        for (int c = 0; c < 4; c++) {
+            if (at_top) w[0][c] = w[1][c];
+            if (at_bot) w[3][c] = w[2][c];
+        }
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if (at_left) w[r][0] = w[r][1];
-        if (at_right) w[r][3] = w[r][2];
+        for (int r = 0; r < 4; r++) {
+            if (at_left) w[r][0] = w[r][1];
+            if (at_right) w[r][3] = w[r][2];
+        }
     }
 }
 
@@ -204,15 +206,17 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
                               {wgb.v[1][0], g2_c, wgb.v[1][1], g2_r},
                               {g1_dl, wgr.v[2][1], g1_d, wgr.v[2][2]}};
             // GaussianBlur border = REFLECT_101 at full resolution: row -1 -> row 1, row H -> row H-2
+            if (at_top | at_bot | at_left | at_right) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (at_top) Wn[0][k] = Wn[2][k];
-                if (at_bot) Wn[3][k] = Wn[1][k];
-            }
+                for (int k = 0; k < 4; k++) {
+                    if (at_top) Wn[0][k] = Wn[2][k];
+                    if (at_bot) Wn[3][k] = Wn[1][k];
+                }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (at_left) Wn[k][0] = Wn[k][2];
-                if (at_right) Wn[k][3] = Wn[k][1];
+                for (int k = 0; k < 4; k++) {
+                    if (at_left) Wn[k][0] = Wn[k][2];
+                    if (at_right) Wn[k][3] = Wn[k][1];
+                }
             }
             float hf[4];
             highpass_quad(Wn, hf);
