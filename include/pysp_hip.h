@@ -111,6 +111,14 @@ int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, co
 int pysp_fuse_raw_f32(pysp_ctx *ctx, const float *const *frames, int K, int H, int W, const float *ev_off, const float *bias, int kmax, float *out, int32_t *count);
 int pysp_fuse_raw_dev(pysp_ctx *ctx, const float *const *d_frames, int K, int H, int W, const float *ev_off, const float *bias, int kmax, float *d_out, int32_t *d_count);
 
+/* raw_hdr.py:7-83 fuse_exposures_from_debayer, pixel loop :54-81, K <= 12 exposures of npx RGB pixels.
+ *   coeff[k*3+c] = exposure._wb_coeff, applied[k] = exposure._wb_applied (image_base.py:31,45-60),
+ *   bias[k] = float32(1.6**(-0.1*ev_off_k)) (:60-61), kmax = last k with ev_off_k == max (:67-68),
+ *   M = final matrix for the trailing cam_to_lin_srgb(clip_highlights=False) (:81) or NULL for none.
+ * write_back != 0 stores into frames[k] the wb_undo/wb_apply round-tripped image the reference leaves
+ * in exposure.image (:56,:65).  out: (npx,3) float32, count: (npx,3) int32. */
+int pysp_fuse_rgb_f32(pysp_ctx *ctx, float *const *frames, int K, size_t npx, const float *coeff, const int *applied, const float *ev_off, const float *bias, int kmax, const double *M, float *out, int32_t *count, int write_back);
+
 /* ---- DNG WarpRectilinear --------------------------------------------------------------------
  * dng_warp_corr/dng_warp_rectilinear_coords.pyx:67-80 compute_remapping_table and :82-96
  * compute_offset_remapping_table (seed != NULL); table: (height,width,2) float32. */

@@ -319,6 +319,31 @@ def fuse_raw(frames: Sequence[np.ndarray], evs: Sequence[float], wb, target_ev: 
     return out, cnt, target, max(offs)
 
 
+def fuse_rgb(images: Sequence[np.ndarray], evs: Sequence[float], coeffs, M=None, applied=None, target_ev: Optional[float] = None):
+    """raw_hdr.py:7-83 on arrays: returns (fused [after CCM if M], count, images as left in the exposures)."""
+    imgs = [_f32(a) for a in images]
+    K = len(imgs); shape = imgs[0].shape
+    evs = [float(e) for e in evs]
+    if target_ev is None:
+        target_ev = 0
+        for e in evs:
+            target_ev += e
+        target_ev /= len(evs)
+    offs = [2 ** (e - target_ev) for e in evs]
+    bias = np.array([1.6 ** (-0.1 * off) for off in offs]).astype(np.float32)          # :60-61
+    kmax = max(k for k, off in enumerate(offs) if off == np.max(offs))                # :67 (last match wins)
+    cf = np.ascontiguousarray(np.broadcast_to(np.asarray(coeffs, dtype=np.float32).reshape(-1, 3), (K, 3)))
+    ap = np.ascontiguousarray(np.ones(K, np.int32) if applied is None else np.asarray(applied, dtype=np.int32))
+    offs32 = np.array(offs, dtype=np.float32)
+    outs = [np.empty_like(a) for a in imgs]
+    out = np.empty(shape, np.float32); cnt = np.empty(shape, np.int32)
+    Mm = None if M is None else np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+    ptrs = (c_f32p * K)(*[_p(a) for a in imgs]); optrs = (c_f32p * K)(*[_p(a) for a in outs])
+    _chk(lib().orc_fuse_rgb(ptrs, K, ctypes.c_size_t(imgs[0].size // 3), _p(cf), _p(ap, ctypes.c_int32), _p(offs32), _p(bias), kmax,
+                            None if Mm is None else _p(Mm, ctypes.c_double), _p(out), _p(cnt, ctypes.c_int32), optrs), "fuse_rgb")
+    return out, cnt, outs
+
+
 def warp_table(kr0, kr1, kr2, kr3, kt0, kt1, width, height, cxn, cyn, scale, seed=None) -> np.ndarray:
     out = np.empty((height, width, 2), np.float32)
     sp = None

@@ -794,6 +794,52 @@ int orc_fuse_raw(const float *const *frames, int K, int H, int W, const float *e
     return ORC_OK;
 }
 
+/* raw_hdr.py:7-83 fuse_exposures_from_debayer, pixel loop :54-81.  frames[k]: (npx,3) float32 images as the
+ * exposures hold them; applied[k]: exposure._wb_applied; coeff[k*3+c]: exposure._wb_coeff; bias[k] =
+ * float32(1.6**(-0.1*ev_off_k)) (:60-61, python float folded into a float32 array).  Per element:
+ *   u = wb_undo  : float32(float64(a) / coeff)  if applied else a          (image_base.py:52-60)
+ *   w = (0.5 - |u - 0.5|) * bias ; sw += w                                   (:58-63)
+ *   v = wb_apply : float32(u * coeff)                                        (image_base.py:45-50)
+ *   sp += (v * w) * ev_off ; count += (w > 0)                                (:70,:72)
+ * out = sw == 0 ? v_kmax * ev_off_kmax : sp / sw (:74-79), then cam_to_lin_srgb(clip=False) (:81) if M.
+ * kmax = LAST exposure whose ev_off equals the maximum (:67-68).  frames_out[k] (optional) receives v,
+ * the state the reference leaves in exposure.image. */
+int orc_fuse_rgb(const float *const *frames, int K, size_t npx, const float *coeff, const int *applied, const float *ev_off,
+                 const float *bias, int kmax, const double *M, float *out, int32_t *count, float *const *frames_out) {
+    if (K <= 0 || kmax < 0 || kmax >= K) return ORC_EBADARG;
+#pragma omp parallel for
+    for (size_t i = 0; i < npx; i++) {
+        float res[3];
+        for (int c = 0; c < 3; c++) {
+            size_t o = 3 * i + c;
+            float sw = 0.0f, sp = 0.0f, vmax = 0.0f;
+            int32_t cnt = 0;
+            for (int k = 0; k < K; k++) {
+                float a = frames[k][o], cf = coeff[k * 3 + c];
+                float u = applied[k] ? (float)((double)a / (double)cf) : a;
+                float w = (0.5f - fabsf(u - 0.5f)) * bias[k];
+                sw = sw + w;
+                float v = u * cf;
+                sp = sp + (v * w) * ev_off[k];
+                if (w > 0.0f) cnt++;
+                if (k == kmax) vmax = v;
+                if (frames_out && frames_out[k]) frames_out[k][o] = v;
+            }
+            float q = sp / sw;
+            res[c] = sw == 0.0f ? vmax * ev_off[kmax] : q;
+            count[o] = cnt;
+        }
+        if (M) {
+            out[3 * i] = ccm_row(M, res[0], res[1], res[2]);
+            out[3 * i + 1] = ccm_row(M + 3, res[0], res[1], res[2]);
+            out[3 * i + 2] = ccm_row(M + 6, res[0], res[1], res[2]);
+        } else {
+            out[3 * i] = res[0]; out[3 * i + 1] = res[1]; out[3 * i + 2] = res[2];
+        }
+    }
+    return ORC_OK;
+}
+
 /* ------------------------------------------------------------------------------------------
  * dng_warp_corr/dng_warp_rectilinear_coords.pyx:18-40,67-80 (+ seeded :44-65,82-96).
  * Cython lowers `x ** k` on C floats to powf(x,k.0) and sqrt() to the double sqrt. table is (H,W,2). */

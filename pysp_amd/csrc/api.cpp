@@ -369,6 +369,31 @@ int pysp_fuse_raw_f32(pysp_ctx* ctx, const float* const* frames, int K, int H, i
     return pysp_ctx_sync(ctx);
 }
 
+int pysp_fuse_rgb_f32(pysp_ctx* ctx, float* const* frames, int K, size_t npx, const float* coeff, const int* applied, const float* ev_off,
+                      const float* bias, int kmax, const double* M, float* out, int32_t* count, int write_back) {
+    CTX_ENTER(ctx);
+    if (!frames || !coeff || !applied || !ev_off || !bias || !out || !count) return fail(PYSP_EBADARG, "fuse_rgb: null pointer");
+    if (K < 1 || K > 12 || kmax < 0 || kmax >= K || npx == 0) return fail(PYSP_EBADARG, "fuse_rgb: 1..12 exposures supported (got %d)", K);
+    size_t bytes = npx * 12;
+    std::vector<const float*> d_in(K);
+    std::vector<float*> d_io(K);
+    for (int k = 0; k < K; k++) {
+        if (!frames[k]) return fail(PYSP_EBADARG, "fuse_rgb: null frame %d", k);
+        float* d; RESERVE(ctx, S_FR0 + k, bytes, d);
+        TRY(h2d(ctx, d, frames[k], bytes));
+        d_in[k] = d; d_io[k] = d;            // in place: each element is read once before it is written
+    }
+    float* d_out; int32_t* d_cnt;
+    RESERVE(ctx, S_OUT, bytes, d_out); RESERVE(ctx, S_AUX, bytes, d_cnt);
+    ctx->tic();
+    LAUNCH_TRY(launch_fuse_rgb(ctx->stream, d_in.data(), write_back ? d_io.data() : nullptr, K, npx, coeff, applied, ev_off, bias, kmax, M, d_out, d_cnt));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, bytes));
+    TRY(d2h(ctx, count, d_cnt, bytes));
+    if (write_back) for (int k = 0; k < K; k++) TRY(d2h(ctx, frames[k], d_io[k], bytes));
+    return pysp_ctx_sync(ctx);
+}
+
 // ---- WarpRectilinear ----------------------------------------------------------------------------------
 int pysp_warp_table_f32(pysp_ctx* ctx, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height, float cx_norm,
                         float cy_norm, float scale, const float* seed, float* table) {

@@ -79,6 +79,70 @@ int launch_fuse_raw(hipStream_t st, const float* const* d_frames, int K, int H, 
     return CHECK_LAUNCH();
 }
 
+// ---- fusion of debayered exposures (raw_hdr.py:7-83) --------------------------------------------------
+// One thread per RGB pixel; see oracle orc_fuse_rgb for the op order.  Optionally applies the CCM
+// (cam_to_lin_srgb, clip off) and writes back the undo/apply round-tripped images.
+struct FuseRgbParams {
+    const float* frames[MAXK];
+    float* frames_out[MAXK];
+    float coeff[MAXK][3];
+    float ev_off[MAXK], bias[MAXK];
+    int applied[MAXK];
+    int K, kmax, use_ccm;
+    size_t npx;
+    Ccm ccm;
+    float* out;
+    int32_t* count;
+};
+__global__ void __launch_bounds__(256) k_fuse_rgb(FuseRgbParams p) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.npx) return;
+    float sw[3] = {0, 0, 0}, sp[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
+    int cnt[3] = {0, 0, 0};
+    for (int k = 0; k < p.K; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float a = p.frames[k][3 * i + c], cf = p.coeff[k][c];
+            float u = p.applied[k] ? (float)((double)a / (double)cf) : a;
+            float w = (0.5f - fabsf(u - 0.5f)) * p.bias[k];
+            sw[c] = sw[c] + w;
+            float v = u * cf;
+            sp[c] = sp[c] + (v * w) * p.ev_off[k];
+            cnt[c] += w > 0.0f ? 1 : 0;
+            if (k == p.kmax) vmax[c] = v;
+            if (p.frames_out[k]) p.frames_out[k][3 * i + c] = v;
+        }
+    }
+    float res[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        res[c] = sw[c] == 0.0f ? vmax[c] * p.ev_off[p.kmax] : sp[c] / sw[c];
+        p.count[3 * i + c] = cnt[c];
+    }
+    if (p.use_ccm) {
+        p.out[3 * i] = ccm_row(p.ccm.m, res[0], res[1], res[2]);
+        p.out[3 * i + 1] = ccm_row(p.ccm.m + 3, res[0], res[1], res[2]);
+        p.out[3 * i + 2] = ccm_row(p.ccm.m + 6, res[0], res[1], res[2]);
+    } else {
+        p.out[3 * i] = res[0]; p.out[3 * i + 1] = res[1]; p.out[3 * i + 2] = res[2];
+    }
+}
+int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int K, size_t npx, const float* coeff,
+                    const int* applied, const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count) {
+    if (K < 1 || K > MAXK || kmax < 0 || kmax >= K) return -1;
+    FuseRgbParams p;
+    for (int k = 0; k < K; k++) {
+        p.frames[k] = d_frames[k];
+        p.frames_out[k] = d_frames_out ? d_frames_out[k] : nullptr;
+        for (int c = 0; c < 3; c++) p.coeff[k][c] = coeff[k * 3 + c];
+        p.ev_off[k] = ev_off[k]; p.bias[k] = bias[k]; p.applied[k] = applied[k];
+    }
+    p.K = K; p.kmax = kmax; p.npx = npx; p.out = d_out; p.count = d_count; p.use_ccm = M != nullptr;
+    for (int i = 0; i < 9; i++) p.ccm.m[i] = M ? M[i] : 0.0;
+    hipLaunchKernelGGL(k_fuse_rgb, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, p);
+    return CHECK_LAUNCH();
+}
+
 // ---- WarpRectilinear ------------------------------------------------------------------------------
 // pyx:18-40.  Cython lowers x**k on C floats to powf(x, k.0) (correctly rounded to float32 by glibc
 // in all but ~0.3 % of arguments) and sqrt to the double sqrt.  Here x**2 is the exact float32

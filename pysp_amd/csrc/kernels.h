@@ -39,6 +39,8 @@ int launch_draft(hipStream_t st, const float* d_bayer, int H, int W, const float
 // k_misc.hip
 int launch_fuse_raw(hipStream_t st, const float* const* d_frames_host_array, int K, int H, int W, const float* ev_off,
                     const float* bias, int kmax, float* d_out, int32_t* d_count);
+int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int K, size_t npx, const float* coeff,
+                    const int* applied, const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count);
 int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
                       float cxn, float cyn, float scale, const float* d_seed, float* d_table);
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,

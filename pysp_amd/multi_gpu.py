@@ -45,3 +45,21 @@ def broadcast_params(wb, M, src: int = 0, device=None):
         t.copy_(torch.from_numpy(pack_params(wb, M)))
     dist.broadcast(t, src=src)
     return unpack_params(t.cpu().numpy())
+
+
+def band_ranges(H: int, n_bands: int, halo: int) -> List[Tuple[int, int, int, int]]:
+    """Intra-frame sharding for one large frame (BASELINE config 5): `n_bands` horizontal bands aligned to
+    even rows.  Returns (y0, y1, r0, r1) per band: rows [y0, y1) are the band's output, rows [r0, r1) are
+    what it reads -- the band plus `halo` rows on each side, clipped at the true image border (where the
+    reference's own border rules apply).  The halo comes from the host-side input (overlapping uploads),
+    so the demosaic needs no GPU-to-GPU exchange.  AHD needs halo >= 8 + 4 * postprocess_stages rows."""
+    if H < 2 or H % 2 or n_bands < 1 or halo < 0 or halo % 2:
+        raise ValueError("H and halo must be even, n_bands >= 1")
+    n_bands = min(n_bands, H // 2)
+    rows = H // 2
+    out = []
+    for b in range(n_bands):
+        y0 = 2 * (rows * b // n_bands)
+        y1 = 2 * (rows * (b + 1) // n_bands)
+        out.append((y0, y1, max(0, y0 - halo), min(H, y1 + halo)))
+    return out

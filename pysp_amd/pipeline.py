@@ -1,0 +1,112 @@
+"""Device-resident pipelines for batch callers (frames stay in HBM; torch is only the allocator).
+
+Each method takes/returns torch CUDA tensors and enqueues on this object's HIP stream through the
+`*_dev` entry points of the C ABI.  Nothing is copied to the host.
+
+    pipe = DevicePipeline(0)
+    srgb = pipe.demosaic_to_srgb(bayer_dev, wb, M)                 # README.md:55-63 recipe, fused
+    srgb = pipe.hdr_stack_to_srgb(frames_dev, evs, cam_wb)          # raw_hdr.py:85-158 + README.md:141-158
+    rgb  = pipe.demosaic_warp(bayer_dev, wb, M, coeffs, centre)     # AHD + dng_warp_corr opcode 1
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .colorize.transform import final_matrix
+
+
+def _dp(t) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class DevicePipeline:
+    def __init__(self, device: int = 0):
+        import torch   # noqa: F401  (imported first so that one HIP runtime serves both)
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.ctx = _lib.Context(device)
+        self.L = _lib.lib()
+
+    # every tensor handed in was produced on torch's current stream: make our stream wait for it
+    def _enter(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def sync(self):
+        self.ctx.sync()
+
+    def _check_bayer(self, bayer):
+        if bayer.dtype != self.torch.float32 or bayer.dim() != 2 or not bayer.is_contiguous() or bayer.device != self.device:
+            raise ValueError("expected a contiguous float32 (H, W) mosaic on this pipeline's device")
+        return int(bayer.shape[0]), int(bayer.shape[1])
+
+    def demosaic(self, bayer, wb, M, quality: int = _lib.QUALITY_BEST, hdr: bool = False, stages: int = 1, out=None):
+        H, W = self._check_bayer(bayer)
+        self._enter()
+        out = self.torch.empty((H, W, 3), dtype=self.torch.float32, device=self.device) if out is None else out
+        _lib.check(self.L.pysp_demosaic_dev(self.ctx.handle, _dp(bayer), H, W, _lib.wb3(wb), _lib.mat9(M), quality, int(hdr), int(stages), _dp(out)))
+        return out
+
+    def demosaic_to_srgb(self, bayer, wb, M, quality: int = _lib.QUALITY_BEST, hdr: bool = False, stages: int = 1, reinhard: bool = False, out=None):
+        H, W = self._check_bayer(bayer)
+        self._enter()
+        out = self.torch.empty((H, W, 3), dtype=self.torch.float32, device=self.device) if out is None else out
+        _lib.check(self.L.pysp_pipeline_srgb_dev(self.ctx.handle, _dp(bayer), H, W, _lib.wb3(wb), _lib.mat9(M), quality, int(hdr), int(stages),
+                                                 int(reinhard), _dp(out)))
+        return out
+
+    def fuse_raw(self, frames: Sequence, evs: Sequence[float], wb, target_ev: Optional[float] = None):
+        """raw_hdr.py:85-158 on device mosaics: returns (fused mosaic, count, target_ev, lim_sat)."""
+        K = len(frames)
+        H, W = self._check_bayer(frames[0])
+        for f in frames:
+            if self._check_bayer(f) != (H, W):
+                raise ValueError("all exposures must share one shape")
+        if target_ev is None:
+            target_ev = 0
+            for ev in evs:
+                target_ev += ev
+            target_ev /= K
+        offs = [2 ** (ev - target_ev) for ev in evs]
+        wbc = np.asarray(wb, dtype=np.float32)
+        site_w = np.array([wbc[0], wbc[1], wbc[2], wbc[1]], dtype=np.float32)
+        bias = np.ascontiguousarray(np.stack([1.6 ** (-0.1 * np.abs(off * site_w)) for off in offs]).astype(np.float32))
+        off32 = np.array(offs, dtype=np.float32)
+        self._enter()
+        fused = self.torch.empty((H, W), dtype=self.torch.float32, device=self.device)
+        count = self.torch.empty((H, W), dtype=self.torch.int32, device=self.device)
+        ptrs = (ctypes.c_void_p * K)(*[f.data_ptr() for f in frames])
+        fp = ctypes.POINTER(ctypes.c_float)
+        _lib.check(self.L.pysp_fuse_raw_dev(self.ctx.handle, ptrs, K, H, W, off32.ctypes.data_as(fp), bias.ctypes.data_as(fp),
+                                            int(np.argmax(offs)), _dp(fused), _dp(count)))
+        return fused, count, target_ev, max(offs)
+
+    def hdr_stack_to_srgb(self, frames: Sequence, evs: Sequence[float], cam_wb, stages: int = 1, out=None):
+        """BASELINE config 4: K exposures -> raw fusion -> AHD (HDR metric) -> to_lin_srgb -> x/(1+x) -> sRGB."""
+        wb = cam_wb.get_reciprocal_multipliers()
+        fused, count, _, _ = self.fuse_raw(frames, evs, wb)
+        M = final_matrix(cam_wb.get_matrix())
+        H, W = int(fused.shape[0]), int(fused.shape[1])
+        out = self.torch.empty((H, W, 3), dtype=self.torch.float32, device=self.device) if out is None else out
+        _lib.check(self.L.pysp_pipeline_srgb_dev(self.ctx.handle, _dp(fused), H, W, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 1, int(stages), 1, _dp(out)))
+        return out, count
+
+    def warp(self, rgb, coeffs, centre: Tuple[float, float], scale: float = 1.0, out=None):
+        """chan_distortion_corr.py:86-97 on a device (H,W,3) image (out of place)."""
+        if rgb.dtype != self.torch.float32 or rgb.dim() != 3 or rgb.shape[2] != 3 or not rgb.is_contiguous():
+            raise ValueError("expected a contiguous float32 (H, W, 3) image")
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1)
+        self._enter()
+        out = self.torch.empty_like(rgb) if out is None else out
+        _lib.check(self.L.pysp_warp_rectilinear_dev(self.ctx.handle, _dp(rgb), _dp(out), H, W, cf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                    cf.size // 6, float(centre[0]), float(centre[1]), float(scale)))
+        return out
+
+    def demosaic_warp(self, bayer, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0):
+        """BASELINE config 5 on one GPU: AHD(postprocess_stages) then per-channel WarpRectilinear."""
+        rgb = self.demosaic(bayer, wb, M, _lib.QUALITY_BEST, False, stages)
+        return self.warp(rgb, coeffs, centre, scale)

@@ -59,6 +59,40 @@ def fuse_exposures_to_raw(in_exposures: List[RawRggbBayerData], target_ev: Optio
     return (hdr_image, count)
 
 
-def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: Optional[float] = None):
-    """Camera-space fusion of debayered exposures (raw_hdr.py:7-83): SURVEY.md 8(f) rank 2, not built yet."""
-    raise NotImplementedError("fuse_exposures_from_debayer is scheduled after the section-8 rows (SURVEY.md 8f rank 2)")
+def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: Optional[float] = None) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """Camera-space fusion of debayered exposures to HDR linear sRGB (+ contribution counts).
+
+    Weights are taken in pure sensor space (wb_undo), pixels are summed white balanced (wb_apply), exactly
+    as raw_hdr.py:54-72 does; like the reference this leaves every exposure white balanced with its image
+    replaced by the undo/apply round trip.  One kernel, including the trailing cam_to_lin_srgb.
+    """
+    valid = [e for e in in_exposures if e.is_valid()]
+    if len(valid) == 0:
+        return None
+    K = len(valid)
+    target_ev, ev_offsets = _ev_offsets([e.current_ev for e in valid], target_ev)
+    shape = in_exposures[0].image.shape
+    if any(e._wb_normalized for e in valid):
+        raise NotImplementedError("normalised white balance (wb_norm=True) is not produced by any demosaic path and is not fused on the GPU")
+    imgs = [np.array(e.image, dtype=np.float32, order="C", copy=True) for e in valid]
+    if any(a.shape != shape for a in imgs):
+        raise ValueError("all exposures must share one shape")
+    coeff = np.ascontiguousarray(np.stack([np.asarray(e._wb_coeff, dtype=np.float32)[:3] for e in valid]))
+    applied = (ctypes.c_int * K)(*[int(bool(e._wb_applied)) for e in valid])
+    bias = np.array([1.6 ** (-0.1 * off) for off in ev_offsets]).astype(np.float32)          # :60-61
+    off32 = np.array(ev_offsets, dtype=np.float32)
+    kmax = max(k for k, off in enumerate(ev_offsets) if off == np.max(ev_offsets))        # :67-68, last match wins
+    from .colorize.transform import final_matrix
+    M = _lib.mat9(final_matrix(in_exposures[0].mat_xyz))
+    fused = np.empty(shape, np.float32)
+    count = np.empty(shape, np.int32)
+    ptrs = (ctypes.c_void_p * K)(*[a.ctypes.data for a in imgs])
+    fp = ctypes.POINTER(ctypes.c_float)
+    _lib.check(_lib.lib().pysp_fuse_rgb_f32(_lib.default_context().handle, ptrs, K, ctypes.c_size_t(imgs[0].size // 3),
+                                            coeff.ctypes.data_as(fp), applied, off32.ctypes.data_as(fp), bias.ctypes.data_as(fp),
+                                            kmax, M, _lib.ptr(fused), _lib.ptr(count), 1))
+    for e, a in zip(valid, imgs):           # the state wb_undo(); wb_apply() leaves behind
+        e.image = a
+        e._wb_applied = True
+        e._wb_normalized = False
+    return (fused, count)

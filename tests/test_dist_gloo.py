@@ -59,3 +59,17 @@ def test_sharding_properties():
     wb = np.array([2.0, 1.0, 1.4285715], np.float32); M = np.random.default_rng(0).standard_normal((3, 3))
     w2, m2 = unpack_params(pack_params(wb, M))
     assert np.array_equal(w2, wb) and np.array_equal(m2, M)
+
+
+def test_band_ranges():
+    from pysp_amd.multi_gpu import band_ranges
+    for H, n, halo in ((8736, 8, 20), (600, 8, 20), (10, 8, 4), (2, 3, 0)):
+        bands = band_ranges(H, n, halo)
+        assert bands[0][0] == 0 and bands[-1][1] == H
+        for (y0, y1, r0, r1), nxt in zip(bands, bands[1:] + [None]):
+            assert y0 % 2 == 0 and y1 % 2 == 0 and y0 < y1 and r0 % 2 == 0 and r1 % 2 == 0
+            assert r0 == max(0, y0 - halo) and r1 == min(H, y1 + halo)
+            if nxt:
+                assert nxt[0] == y1
+    with pytest.raises(ValueError):
+        band_ranges(7, 2, 2)

@@ -129,3 +129,10 @@ def test_g9_fuse_raw(orc):
 def test_g10_warp_apply(orc):
     d, _ = load_golden("g10_warp_apply")
     assert np.array_equal(orc.warp_rectilinear(d["image"], d["coeffs"], d["centre"]), d["warped"])
+
+
+def test_g9_fuse_from_debayer(orc):
+    d, meta = load_golden("g9_fuse_debayer")
+    M = orc.final_matrix(d["xyz2cam"], d["white_xyz"])
+    fused, cnt, _ = orc.fuse_rgb(list(d["rgb"]), meta["evs"], 1.0 / d["mult"], M)
+    assert np.array_equal(fused, d["fused"]) and np.array_equal(cnt, d["count"])
