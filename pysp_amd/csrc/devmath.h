@@ -71,14 +71,14 @@ DEVI float lab_cbrt(float x) {
 }
 DEVI float lab_decode(float v) {
     v = clip01(v);
-    // both sides are evaluated (no divergence); the pow argument is clamped into its domain so the
-    // unused lane value stays finite
+    // both sides are evaluated (no divergence).  v >= 0 after the clip, so u >= 0.052 and the Newton
+    // iteration stays finite even where its result is discarded.
     float u = (v + 0.055f) * 0.9478673f;
-    float p = lab_pow24(fmaxf(u, 0.09f));
+    float p = lab_pow24(u);
     return v <= 0.04045f ? v * 0.07739938f : p;
 }
 DEVI float lab_f(float t) {
-    float c = lab_cbrt(fmaxf(t, 0.008f));
+    float c = lab_cbrt(t);   // for t <= 0.008856 the value (possibly inf/NaN at t = 0) is discarded by the select
     return t > 0.008856f ? c : __builtin_fmaf(7.787f, t, 0.13793103f);
 }
 DEVI void rgb2lab_px(float R, float G, float B, float& L, float& a, float& b) {
@@ -96,7 +96,7 @@ DEVI void rgb2lab_px(float R, float G, float B, float& L, float& a, float& b) {
 // x ** (1/2.4) in the reference is a float32 power with the float32 exponent 0.41666666; the oracle
 // returns the correctly rounded value of that power, and so does this routine, without a float64 pow:
 //   z0 ~ x^(-7/12) from the hardware log2/exp2 approximations (any ~1e-5 accurate seed works),
-//   one float64 Newton-type correction on z^12 * x^7 = 1 (error ~ r^3/32, r ~ 1e-5 -> < 1e-15),
+//   one float64 Newton-type correction on z^12 * x^7 = (x z^2)^6 x = 1 (error ~ r^3/32, r ~ 1e-5 -> < 1e-15),
 //   y = x*z = x^(5/12), then the first-order factor for the exponent difference 0.41666666f - 5/12.
 // Relative error ~6e-15 (measured), i.e. the float32 rounding agrees with the float64 pow on all but
 // a ~1e-7 fraction of inputs.
@@ -104,9 +104,8 @@ DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
     float l2 = __builtin_amdgcn_logf(x);
     float z0 = __builtin_amdgcn_exp2f(-0.5833333f * l2);
     double xd = (double)x, zd = (double)z0;
-    double x2 = xd * xd, x4 = x2 * x2, x7 = (x4 * x2) * xd;
-    double z2 = zd * zd, z4 = z2 * z2, z8 = z4 * z4, z12 = z8 * z4;
-    double r = __builtin_fma(x7, z12, -1.0);
+    double w = xd * (zd * zd), w2 = w * w, w6 = (w2 * w2) * w2;   // x^7 z^12 = (x z^2)^6 x
+    double r = __builtin_fma(w6, xd, -1.0);
     double c = r * __builtin_fma(r, 13.0 / 288.0, -1.0 / 12.0);
     double z = __builtin_fma(zd, c, zd);
     double y = xd * z;
@@ -116,7 +115,7 @@ DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
 }
 DEVI float srgb_encode(float x) {
     x = clip01(x);
-    float p = srgb_pow_5_12(fmaxf(x, 0.003f));
+    float p = srgb_pow_5_12(x);   // x <= 0.0031308 (incl. 0 -> inf/NaN inside) is discarded by the select
     return x <= 0.0031308f ? x * 12.92f : 1.055f * p - 0.055f;
 }
 DEVI float srgb_decode(float x) {

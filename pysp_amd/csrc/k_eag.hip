@@ -12,7 +12,11 @@
 #include "kernels.h"
 
 namespace {
-constexpr int TQX = 32, TQY = 16;
+#ifndef EAG_TQX
+#define EAG_TQX 32
+#define EAG_TQY 16
+#endif
+constexpr int TQX = EAG_TQX, TQY = EAG_TQY;
 constexpr int MWX = TQX + 4, MWY = TQY + 4;   // raw planes, halo 2 quads
 constexpr int GX = TQX + 2, GY = TQY + 2;     // green / difference planes, halo 1 quad
 constexpr int NT = TQX * TQY;                 // 512
@@ -38,6 +42,7 @@ struct EagParams {
     Ccm ccm;
 };
 
+template <bool TINY>
 __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     __shared__ float mw[4][MWY][MWX];
     __shared__ float gq[4][GY][GX];
@@ -49,7 +54,8 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     for (int idx = tid; idx < 4 * MWY * MWX; idx += NT) {
         int ry = idx / (2 * MWX), rx = idx - ry * (2 * MWX);
         int my = ry >> 1, mx = rx >> 1, dy = ry & 1, dx = rx & 1;
-        int qi = b_sym(tq0y - 2 + my, h), qj = b_sym(tq0x - 2 + mx, w);
+        int qi = TINY ? b_sym(tq0y - 2 + my, h) : b_sym1(tq0y - 2 + my, h);
+        int qj = TINY ? b_sym(tq0x - 2 + mx, w) : b_sym1(tq0x - 2 + mx, w);
         int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
         mw[plane][my][mx] = p.bayer[(size_t)(2 * qi + dy) * W + (2 * qj + dx)];
     }
@@ -58,7 +64,8 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     // P1: green at red / blue sites (eag.py:99-121), * wb[1] (:193); D = sub*wb - g (:142,:194)
     for (int idx = tid; idx < GY * GX; idx += NT) {
         int gy = idx / GX, gx = idx - gy * GX;
-        int ri = b_101(tq0y - 1 + gy, h), rj = b_101(tq0x - 1 + gx, w);
+        int ri = TINY ? b_101(tq0y - 1 + gy, h) : b_1011(tq0y - 1 + gy, h);
+        int rj = TINY ? b_101(tq0x - 1 + gx, w) : b_1011(tq0x - 1 + gx, w);
         int a = ri - (tq0y - 2), c = rj - (tq0x - 2);
         if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;
         float gr = delta_mix(mw[P_G2][a - 1][c], mw[P_G2][a][c], mw[P_G1][a][c - 1], mw[P_G1][a][c]) * p.wb[1];
@@ -82,15 +89,17 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
                       {mw[P_G1][my][mx - 1] * wg, wgr.v[1][1], g1_c, wgr.v[1][2]},
                       {wgb.v[1][0], g2_c, wgb.v[1][1], mw[P_G2][my][mx + 1] * wg},
                       {mw[P_G1][my + 1][mx - 1] * wg, wgr.v[2][1], mw[P_G1][my + 1][mx] * wg, wgr.v[2][2]}};
+    if (at_top | at_bot | at_left | at_right) {     // GaussianBlur REFLECT_101 at full resolution (edge waves only)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {     // GaussianBlur REFLECT_101 at full resolution
-        if (at_top) Wn[0][k] = Wn[2][k];
-        if (at_bot) Wn[3][k] = Wn[1][k];
-    }
+        for (int k = 0; k < 4; k++) {
+            if (at_top) Wn[0][k] = Wn[2][k];
+            if (at_bot) Wn[3][k] = Wn[1][k];
+        }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (at_left) Wn[k][0] = Wn[k][2];
-        if (at_right) Wn[k][3] = Wn[k][1];
+        for (int k = 0; k < 4; k++) {
+            if (at_left) Wn[k][0] = Wn[k][2];
+            if (at_right) Wn[k][3] = Wn[k][1];
+        }
     }
     float hf[4], fg[4], fd[4], rr[4], bb[4];
     highpass_quad(Wn, hf);                                           // eag.py:156
@@ -119,7 +128,8 @@ int launch_eag(hipStream_t st, const float* d_bayer, int H, int W, const float w
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
     dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_eag");
-    hipLaunchKernelGGL(k_eag, g, dim3(NT), 0, st, a);
+    if (H / 2 < 4 || W / 2 < 4) hipLaunchKernelGGL(k_eag<true>, g, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL(k_eag<false>, g, dim3(NT), 0, st, a);
     if (tl) tl->end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
