@@ -105,9 +105,9 @@ def main() -> None:
         step(i)
     fence()
 
-    # ---- timed region: exactly K steps; per-kernel HIP events are recorded on the launch stream
-    ctx.set_kernel_timing(True)
-    per_kernel: dict = {}
+    # ---- timed region: exactly K steps, nothing but the kernels on the stream (no event records inside)
+    ctx.set_kernel_timing(0)
+    fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -121,15 +121,15 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations: events of the last timed step, plus a few extra profiled steps for an average
+    # ---- per-kernel durations: the same steps again, each kernel bracketed by HIP events on the launch
+    # stream (recording them inside the timed region would add ~50 us of event traffic to every 1.1 ms step)
+    ctx.set_kernel_timing(2)
     samples: dict = {}
-    for name, ms in ctx.kernel_times():
-        samples.setdefault(name, []).append(ms)
-    for i in range(min(8, args.steps)):
+    for i in range(min(16, max(4, args.steps))):
         step(i)
         for name, ms in ctx.kernel_times():
             samples.setdefault(name, []).append(ms)
-    ctx.set_kernel_timing(False)
+    ctx.set_kernel_timing(1)
     per_kernel = {k: float(np.mean(v)) for k, v in samples.items()}
 
     if rank != 0:

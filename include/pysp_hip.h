@@ -54,10 +54,11 @@ int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
  * the context's stream; waits for completion). */
 int pysp_ctx_last_kernel_ms(pysp_ctx *ctx, float *ms);
-/* Per-kernel timing of the demosaic pipelines: when enabled, each kernel a *_dev / host demosaic or
- * pipeline call enqueues is bracketed by HIP events on the context's stream.  kernel_times returns the
- * durations (ms) and static names of the kernels of the most recent such call (waits for them). */
-int pysp_ctx_set_kernel_timing(pysp_ctx *ctx, int on);
+/* Event timing on the context's stream.  mode 0: no events are recorded (nothing but kernels is enqueued);
+ * mode 1 (default): one event pair per entry-point call (pysp_ctx_last_kernel_ms); mode 2: in addition each
+ * kernel of a demosaic / pipeline call is bracketed by its own pair.  kernel_times returns the durations (ms)
+ * and static names of the kernels of the most recent such call (waits for them). */
+int pysp_ctx_set_kernel_timing(pysp_ctx *ctx, int mode);
 int pysp_ctx_kernel_times(pysp_ctx *ctx, int max_kernels, float *ms, const char **names, int *n_out);
 
 /* ---- Bayer plane helpers -------------------------------------------------------------------- */

@@ -151,8 +151,9 @@ class Context:
         check(lib().pysp_ctx_last_kernel_ms(self.handle, ctypes.byref(ms)))
         return float(ms.value)
 
-    def set_kernel_timing(self, on: bool) -> None:
-        check(lib().pysp_ctx_set_kernel_timing(self.handle, int(bool(on))))
+    def set_kernel_timing(self, mode: int) -> None:
+        """0: record no events; 1: one event pair per call (default); 2: plus one pair per kernel."""
+        check(lib().pysp_ctx_set_kernel_timing(self.handle, int(mode)))
 
     def kernel_times(self):
         """[(kernel name, ms), ...] of the most recent demosaic/pipeline call (kernel timing must be on)."""

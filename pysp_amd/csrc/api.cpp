@@ -49,6 +49,7 @@ struct pysp_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int timing_mode = 1;      // 0: no events, 1: one event pair per call (default), 2: plus one pair per kernel
     static constexpr int NSLOT = 24;
     void* slot[NSLOT] = {};
     size_t cap[NSLOT] = {};
@@ -66,8 +67,8 @@ struct pysp_ctx {
         *out = slot[i];
         return PYSP_OK;
     }
-    void tic() { tl.n = 0; if (hipEventRecord(ev0, stream) == hipSuccess) timed = false; }
-    void toc() { if (hipEventRecord(ev1, stream) == hipSuccess) timed = true; }
+    void tic() { tl.n = 0; timed = false; if (timing_mode) (void)hipEventRecord(ev0, stream); }
+    void toc() { if (timing_mode && hipEventRecord(ev1, stream) == hipSuccess) timed = true; }
 };
 
 #define CTX_ENTER(ctx)                                                   \
@@ -139,10 +140,13 @@ int pysp_ctx_last_kernel_ms(pysp_ctx* ctx, float* ms) {
     return PYSP_OK;
 }
 
-int pysp_ctx_set_kernel_timing(pysp_ctx* ctx, int on) {
+int pysp_ctx_set_kernel_timing(pysp_ctx* ctx, int mode) {
     CTX_ENTER(ctx);
-    ctx->tl.on = on != 0;
+    if (mode < 0 || mode > 2) return fail(PYSP_EBADARG, "kernel timing mode must be 0, 1 or 2");
+    ctx->timing_mode = mode;
+    ctx->tl.on = mode == 2;
     ctx->tl.n = 0;
+    ctx->timed = false;
     return PYSP_OK;
 }
 

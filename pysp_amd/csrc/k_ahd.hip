@@ -326,22 +326,40 @@ constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // r-g, b-g planes (halo 4)
 constexpr int B2X = BTX + 4, B2Y = BTY + 4;     // g-r', g-b' planes (halo 2)
 constexpr int NT_B = 256;
 
-// Median of 25 by a selection network (exact; order independent).  It is the classic 99-exchange
-// network; wherever three exchanges (b,c),(a,c),(a,b) fully sort a triple they are issued as one
-// v_min3 / v_med3 / v_max3 group (3 VALU ops instead of 6).  Exhaustive 0-1 check: tools/check_median25.c.
-// Two independent windows are pushed through the network in lockstep: the network is one long
-// dependency chain, and the second window fills its issue bubbles.
+// Median of 25 by a selection network (exact; order independent): the classic 99-exchange network;
+// wherever three exchanges (b,c),(a,c),(a,b) fully sort a triple they are issued as one v_min3 / v_med3 /
+// v_max3 group (3 VALU ops instead of 6; on gfx950 min/max/med3 issue at 4 cycles per wave, so the
+// count of these ops is what bounds the kernel).  Exhaustive 0-1 check: tools/check_median25.c.
+// The kernel always handles a horizontally adjacent pixel pair: the two 5x5 windows share 20 elements, the
+// 13 exchanges that involve only those are evaluated once (-17 % ops), the rest runs on both in lockstep.
 #define CE1(v, a, b) { float _t = fminf(v[a], v[b]); v[b] = fmaxf(v[a], v[b]); v[a] = _t; }
 #define S31(v, a, b, c) { float _lo = fminf(fminf(v[a], v[b]), v[c]); float _hi = fmaxf(fmaxf(v[a], v[b]), v[c]); \
                           float _md = __builtin_amdgcn_fmed3f(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
-#define CE(a, b) { CE1(v, a, b) CE1(u, a, b) }
-#define S3(a, b, c) { S31(v, a, b, c) S31(u, a, b, c) }
-DEVI void median25x2(float v[25], float u[25], float& mv, float& mu) {
-#include "median25_network.inc"
-    mv = v[12]; mu = u[12];
-}
+// w: 5 rows x 6 columns; left pixel = columns 0..4, right pixel = columns 1..5
+DEVI void median25_pair(const float w[5][6], float& ml, float& mr) {
+    float v[25], u[25];
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) {
+#pragma unroll
+        for (int dx = 0; dx < 4; dx++) v[dy * 4 + dx] = w[dy][dx + 1];   // wires 0..19: the shared columns
+        v[20 + dy] = w[dy][0];
+    }
+#define CE(a, b) CE1(v, a, b)
+#define S3(a, b, c) S31(v, a, b, c)
+#include "median25_shared.inc"
 #undef CE
 #undef S3
+#pragma unroll
+    for (int k = 0; k < 20; k++) u[k] = v[k];
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) u[20 + dy] = w[dy][5];
+#define CE(a, b) { CE1(v, a, b) CE1(u, a, b) }
+#define S3(a, b, c) { S31(v, a, b, c) S31(u, a, b, c) }
+#include "median25_rest.inc"
+#undef CE
+#undef S3
+    ml = v[12]; mr = u[12];
+}
 #undef CE1
 #undef S31
 }  // namespace
@@ -355,15 +373,13 @@ struct MedParams {
 };
 
 // Window of a horizontally adjacent pixel pair: 5 rows x 6 columns starting at an even column -> three
-// 8-byte LDS reads per row.  v = window of the left pixel, u = window of the right pixel.
-DEVI void load_pair_windows(const float* plane, int stride, int ly, int lx, float v[25], float u[25]) {
+// 8-byte LDS reads per row.
+DEVI void load_pair_window(const float* plane, int stride, int ly, int lx, float w[5][6]) {
 #pragma unroll
     for (int dy = 0; dy < 5; dy++) {
         const float2* row = reinterpret_cast<const float2*>(plane + (ly + dy) * stride + lx);
         float2 a = row[0], b = row[1], c = row[2];
-        float w[6] = {a.x, a.y, b.x, b.y, c.x, c.y};
-#pragma unroll
-        for (int dx = 0; dx < 5; dx++) { v[dy * 5 + dx] = w[dx]; u[dy * 5 + dx] = w[dx + 1]; }
+        w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = c.x; w[dy][5] = c.y;
     }
 }
 
@@ -388,13 +404,13 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         int oy = idx / (B2X / 2), ox = 2 * (idx - oy * (B2X / 2));
         int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
         if (y < 0 || y >= H || x < 0 || x >= W) continue;       // filled from the clamped position below
-        float v[25], u[25], m0, m1;
-        load_pair_windows(&s_drg[0][0], B4X, oy, ox, v, u);
-        median25x2(v, u, m0, m1);
+        float w[5][6], m0, m1;
+        load_pair_window(&s_drg[0][0], B4X, oy, ox, w);
+        median25_pair(w, m0, m1);
         float g0 = s_g[oy + 2][ox + 2], g1 = s_g[oy + 2][ox + 3];
         float r0 = m0 + g0, r1 = m1 + g1;
-        load_pair_windows(&s_dbg[0][0], B4X, oy, ox, v, u);
-        median25x2(v, u, m0, m1);
+        load_pair_window(&s_dbg[0][0], B4X, oy, ox, w);
+        median25_pair(w, m0, m1);
         float b0 = m0 + g0, b1 = m1 + g1;
         *reinterpret_cast<float2*>(&s_r1[oy][ox]) = make_float2(r0, r1);
         *reinterpret_cast<float2*>(&s_b1[oy][ox]) = make_float2(b0, b1);
@@ -419,11 +435,11 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         int ly = idx / (BTX / 2), lx = 2 * (idx - ly * (BTX / 2));
         int y = ty0 + ly, x = tx0 + lx;
         if (y >= H || x >= W) continue;
-        float v[25], u[25], ma0, ma1, mb0, mb1;
-        load_pair_windows(&s_d1[0][0], B2X, ly, lx, v, u);
-        median25x2(v, u, ma0, ma1);
-        load_pair_windows(&s_d2[0][0], B2X, ly, lx, v, u);
-        median25x2(v, u, mb0, mb1);
+        float w[5][6], ma0, ma1, mb0, mb1;
+        load_pair_window(&s_d1[0][0], B2X, ly, lx, w);
+        median25_pair(w, ma0, ma1);
+        load_pair_window(&s_d2[0][0], B2X, ly, lx, w);
+        median25_pair(w, mb0, mb1);
         float2 rr = *reinterpret_cast<const float2*>(&s_r1[ly + 2][lx + 2]);
         float2 bb = *reinterpret_cast<const float2*>(&s_b1[ly + 2][lx + 2]);
         float r0 = rr.x, b0 = bb.x, r1 = rr.y, b1 = bb.y;
