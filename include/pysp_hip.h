@@ -104,6 +104,13 @@ int pysp_wb_scale_f32(pysp_ctx *ctx, const float *in, size_t npx, const float co
 int pysp_pipeline_srgb_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *srgb);
 int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *d_srgb);
 
+/* The same pipelines fed by the raw uint16 mosaic: normalization.py:4-24 (clip(x-black_c,0,sat_c)/sat_c, CFA
+ * sites indexed r,g1,b,g2) is fused into the tile loader, so the float32 mosaic never exists in memory
+ * (image.py:229 followed by :156-183).  tail: 0 camera RGB (RawDemosaicData.image), 1 to_lin_srgb,
+ * 2 + lin_srgb_to_srgb, 3 with x/(1+x) in between. */
+int pysp_pipeline_u16_f32(pysp_ctx *ctx, const uint16_t *bayer, int H, int W, const float black[4], const float sat[4], const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *out);
+int pysp_pipeline_u16_dev(pysp_ctx *ctx, const uint16_t *d_bayer, int H, int W, const float black[4], const float sat[4], const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *d_out);
+
 /* ---- HDR raw fusion -------------------------------------------------------------------------
  * raw_hdr.py:85-158 fuse_exposures_to_raw, pixel loop :135-148.  The host computes, with NumPy as
  * the reference does, ev_off[k] = float32(2**(ev_k-target)) (:119-121), bias[k*4+c] =

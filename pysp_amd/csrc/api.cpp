@@ -10,6 +10,7 @@
 
 #include "../../include/pysp_hip.h"
 #include "kernels.h"
+#include "demosaic_common.h"
 
 namespace {
 
@@ -236,9 +237,9 @@ int pysp_build_map_f32(pysp_ctx* ctx, const float* lab, int Hp, int Wp, int k_pa
 }
 
 // ---- demosaic / fused pipeline ----------------------------------------------------------------------
-static int run_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
+static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
                             int stages, int tail, float* d_out) {
-    if (!d_bayer || !d_out || !wb) return fail(PYSP_EBADARG, "demosaic: null pointer");
+    if ((!src.f32 && !src.u16) || !d_out || !wb) return fail(PYSP_EBADARG, "demosaic: null pointer");
     if (!even_dims(H, W)) return fail(PYSP_EBADARG, "demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
     static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (!M) {
@@ -251,16 +252,21 @@ static int run_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, c
         size_t bytes = (size_t)H * W * 12;
         if (stages >= 1) RESERVE(ctx, S_TMP0, bytes, t0);
         if (stages >= 2) RESERVE(ctx, S_TMP1, bytes, t1);
-        LAUNCH_TRY(launch_ahd(ctx->stream, d_bayer, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, &ctx->tl));
+        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, &ctx->tl));
     } else if (quality == PYSP_QUALITY_FAST) {
-        LAUNCH_TRY(launch_eag(ctx->stream, d_bayer, H, W, wb, M, tail, d_out, &ctx->tl));
+        LAUNCH_TRY(launch_eag(ctx->stream, src, H, W, wb, M, tail, d_out, &ctx->tl));
     } else if (quality == PYSP_QUALITY_DRAFT) {
-        LAUNCH_TRY(launch_draft(ctx->stream, d_bayer, H, W, wb, M, tail, d_out, &ctx->tl));
+        LAUNCH_TRY(launch_draft(ctx->stream, src, H, W, wb, M, tail, d_out, &ctx->tl));
     } else {
         return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
     }
     ctx->toc();
     return PYSP_OK;
+}
+static int run_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
+                            int stages, int tail, float* d_out) {
+    if (!d_bayer) return fail(PYSP_EBADARG, "demosaic: null pointer");
+    return run_pipeline_src(ctx, mosaic_f32(d_bayer), H, W, wb, M, quality, hdr, stages, tail, d_out);
 }
 static int run_pipeline_host(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
                              int stages, int tail, float* out) {
@@ -289,6 +295,27 @@ int pysp_pipeline_srgb_f32(pysp_ctx* ctx, const float* bayer, int H, int W, cons
 int pysp_pipeline_srgb_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float* d_srgb) {
     CTX_ENTER(ctx);
     return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, reinhard ? 3 : 2, d_srgb);
+}
+
+int pysp_pipeline_u16_dev(pysp_ctx* ctx, const uint16_t* d_bayer, int H, int W, const float black[4], const float sat[4], const float wb[3],
+                          const double M[9], int quality, int hdr, int stages, int tail, float* d_out) {
+    CTX_ENTER(ctx);
+    if (!d_bayer || !black || !sat) return fail(PYSP_EBADARG, "pipeline_u16: null pointer");
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_u16: tail must be 0..3");
+    return run_pipeline_src(ctx, mosaic_u16(d_bayer, black, sat), H, W, wb, M, quality, hdr, stages, tail, d_out);
+}
+int pysp_pipeline_u16_f32(pysp_ctx* ctx, const uint16_t* bayer, int H, int W, const float black[4], const float sat[4], const float wb[3],
+                          const double M[9], int quality, int hdr, int stages, int tail, float* out) {
+    CTX_ENTER(ctx);
+    if (!bayer || !out) return fail(PYSP_EBADARG, "pipeline_u16: null pointer");
+    if (!even_dims(H, W)) return fail(PYSP_EBADARG, "pipeline_u16: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
+    size_t N = (size_t)H * W;
+    uint16_t* d_in; float* d_out;
+    RESERVE(ctx, S_IN, N * 2, d_in); RESERVE(ctx, S_OUT, N * 12, d_out);
+    TRY(h2d(ctx, d_in, bayer, N * 2));
+    TRY(pysp_pipeline_u16_dev(ctx, d_in, H, W, black, sat, wb, M, quality, hdr, stages, tail, d_out));
+    TRY(d2h(ctx, out, d_out, N * 12));
+    return pysp_ctx_sync(ctx);
 }
 
 // ---- colour ---------------------------------------------------------------------------------------

@@ -6,6 +6,24 @@
 
 constexpr float GK0 = 0.45186276f, GK1 = 0.27406862f;   // GaussianBlur((3,3), 1.0) taps
 
+// Mosaic source of the tile loaders: float32 sensor_scaled, or the raw uint16 mosaic with
+// normalization.py:4-24 (clip(x - black_c, 0, sat_c) / sat_c, CFA sites indexed r,g1,b,g2) fused in
+// (2 B/px of input traffic instead of 4).
+struct MosaicSrc {
+    const float* f32;
+    const uint16_t* u16;
+    float black[4], sat[4];
+};
+template <bool U16>
+DEVI float load_mosaic(const MosaicSrc& m, size_t idx, int site) {
+    if (U16) {
+        float v = (float)m.u16[idx] - m.black[site];
+        v = v < 0.0f ? 0.0f : (v > m.sat[site] ? m.sat[site] : v);
+        return v / m.sat[site];
+    }
+    return m.f32[idx];
+}
+
 struct Win3 { float v[3][3]; };
 
 template <int STRIDE>

@@ -115,7 +115,7 @@ static_assert(12 * TQX * TQY <= 4 * MWY * MWX + 4 * GY * GX, "rgb_h stash must f
 }  // namespace
 
 struct AhdParams {
-    const float* bayer;
+    MosaicSrc src;
     float* out;          // (H,W,3)
     int H, W;
     float wb[3];
@@ -125,7 +125,7 @@ struct AhdParams {
 };
 
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
-template <bool TINY>
+template <bool TINY, bool U16>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
     // planes: mosaic (dead after P1), then green/difference planes direction-major (direction 0 dead after its
     // P2).  The front of this array is reused for the horizontal RGB candidates while the vertical pass runs.
@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         int qj = TINY ? b_sym(tq0x - 3 + mx, w) : b_sym1(tq0x - 3 + mx, w);
         int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
         float wbv = plane == P_R ? p.wb[0] : (plane == P_B ? p.wb[2] : p.wb[1]);
-        mw[(plane * MWY + my) * MWX + mx] = p.bayer[(size_t)(2 * qi + dy) * W + (2 * qj + dx)] * wbv;
+        int site = dy ? (dx ? 2 : 3) : (dx ? 1 : 0);   // r,g1,b,g2
+        mw[(plane * MWY + my) * MWX + mx] = load_mosaic<U16>(p.src, (size_t)(2 * qi + dy) * W + (2 * qj + dx), site) * wbv;
     }
     __syncthreads();
 
@@ -455,10 +456,10 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-int launch_ahd(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
+int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, Timeline* tl) {
     AhdParams a;
-    a.bayer = d_bayer; a.H = H; a.W = W; a.hdr = hdr;
+    a.src = src; a.H = H; a.W = W; a.hdr = hdr;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M[i];
     if (stages < 0) stages = 0;
@@ -468,8 +469,11 @@ int launch_ahd(hipStream_t st, const float* d_bayer, int H, int W, const float w
     a.tail = stages == 0 ? tail : 0;
     dim3 ga((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_ahd_select");
-    if (H / 2 < 4 || W / 2 < 4) hipLaunchKernelGGL(k_ahd_select<true>, ga, dim3(NT_A), 0, st, a);
-    else hipLaunchKernelGGL(k_ahd_select<false>, ga, dim3(NT_A), 0, st, a);
+    const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
+    if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true>), ga, dim3(NT_A), 0, st, a);
+    else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false>), ga, dim3(NT_A), 0, st, a);
+    else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true>), ga, dim3(NT_A), 0, st, a);
+    else hipLaunchKernelGGL((k_ahd_select<false, false>), ga, dim3(NT_A), 0, st, a);
     if (tl) tl->end(st);
     const float* cur = a.out;
     dim3 gb((W + BTX - 1) / BTX, (H + BTY - 1) / BTY);

@@ -34,7 +34,7 @@ DEVI float delta_mix(float top, float bottom, float left, float right) {
 }  // namespace
 
 struct EagParams {
-    const float* bayer;
+    MosaicSrc src;
     float* out;
     int H, W;
     float wb[3];
@@ -42,7 +42,7 @@ struct EagParams {
     Ccm ccm;
 };
 
-template <bool TINY>
+template <bool TINY, bool U16>
 __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     __shared__ float mw[4][MWY][MWX];
     __shared__ float gq[4][GY][GX];
@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
         int qi = TINY ? b_sym(tq0y - 2 + my, h) : b_sym1(tq0y - 2 + my, h);
         int qj = TINY ? b_sym(tq0x - 2 + mx, w) : b_sym1(tq0x - 2 + mx, w);
         int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
-        mw[plane][my][mx] = p.bayer[(size_t)(2 * qi + dy) * W + (2 * qj + dx)];
+        int site = dy ? (dx ? 2 : 3) : (dx ? 1 : 0);   // r,g1,b,g2
+        mw[plane][my][mx] = load_mosaic<U16>(p.src, (size_t)(2 * qi + dy) * W + (2 * qj + dx), site);
     }
     __syncthreads();
 
@@ -121,15 +122,18 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     }
 }
 
-int launch_eag(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
+int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
     EagParams a;
-    a.bayer = d_bayer; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
+    a.src = src; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
     dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_eag");
-    if (H / 2 < 4 || W / 2 < 4) hipLaunchKernelGGL(k_eag<true>, g, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL(k_eag<false>, g, dim3(NT), 0, st, a);
+    const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
+    if (tiny && u16) hipLaunchKernelGGL((k_eag<true, true>), g, dim3(NT), 0, st, a);
+    else if (tiny) hipLaunchKernelGGL((k_eag<true, false>), g, dim3(NT), 0, st, a);
+    else if (u16) hipLaunchKernelGGL((k_eag<false, true>), g, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((k_eag<false, false>), g, dim3(NT), 0, st, a);
     if (tl) tl->end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -138,12 +142,13 @@ int launch_eag(hipStream_t st, const float* d_bayer, int H, int W, const float w
 // Draft (fast_resize.py:21-39): quarter-resolution RGB with 3/4-1/4 diagonal R/B alignment, then
 // bilinear x2 (half-pixel centres, edge clamp; horizontal pass then vertical pass).
 namespace {
-DEVI void draft_q(const float* __restrict__ bay, int h, int w, int W, int i, int j, const float wb[3], float q[3]) {
+template <bool U16>
+DEVI void draft_q(const MosaicSrc& bay, int h, int w, int W, int i, int j, const float wb[3], float q[3]) {
     int i1 = i + 1 < h ? i + 1 : h - 1, j1 = j + 1 < w ? j + 1 : w - 1;   // r padded bottom/right (REFLECT)
     int i0 = i > 0 ? i - 1 : 0, j0 = j > 0 ? j - 1 : 0;                   // b padded top/left
-    float r = bay[(size_t)(2 * i) * W + 2 * j], rd = bay[(size_t)(2 * i1) * W + 2 * j1];
-    float b = bay[(size_t)(2 * i + 1) * W + 2 * j + 1], bd = bay[(size_t)(2 * i0 + 1) * W + 2 * j0 + 1];
-    float g1 = bay[(size_t)(2 * i) * W + 2 * j + 1], g2 = bay[(size_t)(2 * i + 1) * W + 2 * j];
+    float r = load_mosaic<U16>(bay, (size_t)(2 * i) * W + 2 * j, 0), rd = load_mosaic<U16>(bay, (size_t)(2 * i1) * W + 2 * j1, 0);
+    float b = load_mosaic<U16>(bay, (size_t)(2 * i + 1) * W + 2 * j + 1, 2), bd = load_mosaic<U16>(bay, (size_t)(2 * i0 + 1) * W + 2 * j0 + 1, 2);
+    float g1 = load_mosaic<U16>(bay, (size_t)(2 * i) * W + 2 * j + 1, 1), g2 = load_mosaic<U16>(bay, (size_t)(2 * i + 1) * W + 2 * j, 3);
     q[0] = (0.75f * r + 0.25f * rd) * wb[0];
     q[1] = ((g1 + g2) / 2.0f) * wb[1];
     q[2] = (0.75f * b + 0.25f * bd) * wb[2];
@@ -158,6 +163,7 @@ DEVI void lin_tap(int X, int n, int& s0, int& s1, float& a0, float& a1) {
 }
 }  // namespace
 
+template <bool U16>
 __global__ void __launch_bounds__(256) k_draft(EagParams p) {
     int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
@@ -166,8 +172,8 @@ __global__ void __launch_bounds__(256) k_draft(EagParams p) {
     lin_tap(X, w, sx0, sx1, a0, a1);
     lin_tap(Y, h, sy0, sy1, b0, b1);
     float q00[3], q01[3], q10[3], q11[3];
-    draft_q(p.bayer, h, w, W, sy0, sx0, p.wb, q00); draft_q(p.bayer, h, w, W, sy0, sx1, p.wb, q01);
-    draft_q(p.bayer, h, w, W, sy1, sx0, p.wb, q10); draft_q(p.bayer, h, w, W, sy1, sx1, p.wb, q11);
+    draft_q<U16>(p.src, h, w, W, sy0, sx0, p.wb, q00); draft_q<U16>(p.src, h, w, W, sy0, sx1, p.wb, q01);
+    draft_q<U16>(p.src, h, w, W, sy1, sx0, p.wb, q10); draft_q<U16>(p.src, h, w, W, sy1, sx1, p.wb, q11);
     float o[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -179,14 +185,28 @@ __global__ void __launch_bounds__(256) k_draft(EagParams p) {
     d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
 }
 
-int launch_draft(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
+int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
     EagParams a;
-    a.bayer = d_bayer; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
+    a.src = src; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
     dim3 g((W + 255) / 256, H);
     if (tl) tl->begin(st, "k_draft");
-    hipLaunchKernelGGL(k_draft, g, dim3(256), 0, st, a);
+    if (src.u16) hipLaunchKernelGGL(k_draft<true>, g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_draft<false>, g, dim3(256), 0, st, a);
     if (tl) tl->end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+MosaicSrc mosaic_f32(const float* d_bayer) {
+    MosaicSrc m;
+    m.f32 = d_bayer; m.u16 = nullptr;
+    for (int i = 0; i < 4; i++) { m.black[i] = 0.0f; m.sat[i] = 1.0f; }
+    return m;
+}
+MosaicSrc mosaic_u16(const uint16_t* d_bayer, const float black[4], const float sat[4]) {
+    MosaicSrc m;
+    m.f32 = nullptr; m.u16 = d_bayer;
+    for (int i = 0; i < 4; i++) { m.black[i] = black[i]; m.sat[i] = sat[i]; }
+    return m;
 }

@@ -5,6 +5,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+struct MosaicSrc;   // demosaic_common.h: float32 mosaic, or raw uint16 + black/saturation levels
+MosaicSrc mosaic_f32(const float* d_bayer);
+MosaicSrc mosaic_u16(const uint16_t* d_bayer, const float black[4], const float sat[4]);
+
 // Optional per-kernel timing: when `on`, every launcher brackets each kernel it enqueues with events.
 struct Timeline {
     static constexpr int MAXK = 8;
@@ -29,12 +33,12 @@ int launch_colour_tail(hipStream_t st, const float* in, size_t npx, const double
 
 // k_ahd.hip: tail = colour tail of devmath.h (0 none, 1 lin sRGB, 2 sRGB, 3 Reinhard + sRGB);
 // d_tmp0/d_tmp1 are (H,W,3) scratch images (only needed when stages >= 1 / >= 2).
-int launch_ahd(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
+int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, Timeline* tl = nullptr);
 
 // k_eag.hip
-int launch_eag(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
-int launch_draft(hipStream_t st, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
+int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
+int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
 
 // k_misc.hip
 int launch_fuse_raw(hipStream_t st, const float* const* d_frames_host_array, int K, int H, int W, const float* ev_off,

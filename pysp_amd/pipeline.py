@@ -58,6 +58,21 @@ class DevicePipeline:
                                                  int(reinhard), _dp(out)))
         return out
 
+    def raw_u16_to_rgb(self, raw_u16, black, sat, wb, M, quality: int = _lib.QUALITY_BEST, stages: int = 1, tail: int = 2, out=None):
+        """uint16 sensor mosaic -> normalise (normalization.py:4-24, fused into the tile loader) -> demosaic ->
+        colour tail (0 camera RGB, 1 linear sRGB, 2 sRGB, 3 Reinhard + sRGB).  2 B/px of input traffic."""
+        if raw_u16.dtype != self.torch.uint16 and raw_u16.dtype != self.torch.int16:
+            raise ValueError("expected a uint16 (H, W) mosaic")
+        if raw_u16.dim() != 2 or not raw_u16.is_contiguous() or raw_u16.device != self.device:
+            raise ValueError("expected a contiguous (H, W) mosaic on this pipeline's device")
+        H, W = int(raw_u16.shape[0]), int(raw_u16.shape[1])
+        self._enter()
+        out = self.torch.empty((H, W, 3), dtype=self.torch.float32, device=self.device) if out is None else out
+        bl = (ctypes.c_float * 4)(*[float(black[i]) for i in range(4)])
+        sa = (ctypes.c_float * 4)(*[float(sat[i]) for i in range(4)])
+        _lib.check(self.L.pysp_pipeline_u16_dev(self.ctx.handle, _dp(raw_u16), H, W, bl, sa, _lib.wb3(wb), _lib.mat9(M), quality, 0, int(stages), int(tail), _dp(out)))
+        return out
+
     def fuse_raw(self, frames: Sequence, evs: Sequence[float], wb, target_ev: Optional[float] = None):
         """raw_hdr.py:85-158 on device mosaics: returns (fused mosaic, count, target_ev, lim_sat)."""
         K = len(frames)

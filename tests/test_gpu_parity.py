@@ -396,3 +396,29 @@ def test_config5_ahd3_warp_and_band_tiling(orc, wbobj):
         part = pipe.demosaic(dbay[r0:r1].contiguous(), wb, M, stages=3)
         pipe.sync()
         assert np.array_equal(part.cpu().numpy()[y0 - r0:y1 - r0], whole[y0:y1]), (y0, y1)
+
+
+def test_uint16_fused_loader(orc, wbobj):
+    """bayer_normalize fused into the tile loaders of all three demosaic kernels."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.normalization import raw_to_rgb
+    from pysp_amd.pipeline import DevicePipeline
+    wb, M = _wbM(orc)
+    rng = np.random.default_rng(21)
+    black, sat = [64, 64, 66, 64], [4095, 4000, 4095, 4095]
+    for (H, W) in ((2, 6), (66, 130), (300, 420)):
+        raw = rng.integers(0, 4500, (H, W), dtype=np.uint16)
+        norm = orc.bayer_normalize(raw, black, sat)
+        assert np.array_equal(raw_to_rgb(raw, black, sat, wbobj, _lib.QUALITY_DRAFT), orc.demosaic_draft(norm, wb))
+        assert np.array_equal(raw_to_rgb(raw, black, sat, wbobj, _lib.QUALITY_FAST), orc.demosaic_eag(norm, wb))
+        for st in (0, 1):
+            assert np.array_equal(raw_to_rgb(raw, black, sat, wbobj, _lib.QUALITY_BEST, st), orc.demosaic_ahd(norm, wb, M, False, st))
+        u = ulp_diff(raw_to_rgb(raw, black, sat, wbobj, _lib.QUALITY_BEST, 1, tail=2), orc.pipeline_srgb(norm, wb, M, 2, False, 1, False))
+        assert u.max() <= 1 and np.mean(u != 0) < 1e-3
+    pipe = DevicePipeline(0)
+    raw = rng.integers(0, 4500, (512, 768), dtype=np.uint16)
+    out = pipe.raw_u16_to_rgb(torch.from_numpy(raw.view(np.int16)).cuda().view(torch.uint16), black, sat, wb, M, tail=1)
+    pipe.sync()
+    norm = orc.bayer_normalize(raw, black, sat)
+    assert np.array_equal(out.cpu().numpy(), orc.cam_to_rgb(orc.demosaic_ahd(norm, wb, M, False, 1), M, True))
