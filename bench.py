@@ -34,6 +34,9 @@ WORKLOADS = {
     "ahd24": (4000, 6000, 2, 1, "24MP RGGB, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb"),
     "eag24": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + to_lin_srgb + lin_srgb_to_srgb"),
     "draft12": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + to_lin_srgb + lin_srgb_to_srgb"),
+    # secondary kernels (BASELINE configs 4 and 5), reported with their own algorithmic bytes
+    "fuse45": (5464, 8192, -1, 0, "raw_hdr fuse_exposures_to_raw, 7 x 45MP exposures -> HDR mosaic + count (36 B per output px)"),
+    "warp100": (8736, 11648, -2, 0, "100MP RGB, DNG WarpRectilinear per-channel Lanczos-4 remap (24 B/px)"),
 }
 
 
@@ -82,18 +85,48 @@ def main() -> None:
     wb = _lib.wb3(wb_np)
     M = _lib.mat9(M_np)
 
-    # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
-    frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
-    out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
-
     ctx = _lib.Context(local_rank)            # own HIP stream; kernels are timed with events on THAT stream
     L = _lib.lib()
+    alg_bytes_per_px = ALG_BYTES_PER_PX
 
-    def step(i: int) -> None:
-        f = frames[i % len(frames)]
-        _lib.check(L.pysp_pipeline_srgb_dev(ctx.handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, 0,
-                                            ctypes.c_void_p(out.data_ptr())))
+    if quality >= 0:
+        # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
+        frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
+        out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+
+        def step(i: int) -> None:
+            f = frames[i % len(frames)]
+            _lib.check(L.pysp_pipeline_srgb_dev(ctx.handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, 0,
+                                                ctypes.c_void_p(out.data_ptr())))
+    elif quality == -1:
+        K = 7
+        base = rggb_frame(H, W, 1000 + rank, scale=8.0, clip_hi=False)
+        frames = [torch.from_numpy(np.clip(base * np.float32(2.0 ** -k), 0, 1)).to(dev) for k in range(K)]
+        del base
+        out = torch.empty((H, W), dtype=torch.float32, device=dev)
+        cnt = torch.empty((H, W), dtype=torch.int32, device=dev)
+        offs = [2.0 ** (10 + k - 13.0) for k in range(K)]
+        site_w = np.array([wb_np[0], wb_np[1], wb_np[2], wb_np[1]], dtype=np.float32)
+        bias = np.ascontiguousarray(np.stack([1.6 ** (-0.1 * np.abs(o * site_w)) for o in offs]).astype(np.float32))
+        off32 = np.array(offs, dtype=np.float32)
+        ptrs = (ctypes.c_void_p * K)(*[f.data_ptr() for f in frames])
+        fp = ctypes.POINTER(ctypes.c_float)
+        alg_bytes_per_px = 4 * K + 8
+
+        def step(i: int) -> None:
+            _lib.check(L.pysp_fuse_raw_dev(ctx.handle, ptrs, K, H, W, off32.ctypes.data_as(fp), bias.ctypes.data_as(fp), K - 1,
+                                           ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(cnt.data_ptr())))
+    else:
+        frames = [torch.rand((H, W, 3), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(1000 + rank))]
+        out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        coeffs = np.array([[1.0, 0.01, 0.002, 0.0, 0.0, 0.0], [1.0, 0.0, 0.002, 0.0, 0.0, 0.0], [1.0, -0.01, 0.002, 0.0, 0.0, 0.0]])
+        cptr = coeffs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        alg_bytes_per_px = 24
+
+        def step(i: int) -> None:
+            _lib.check(L.pysp_warp_rectilinear_dev(ctx.handle, ctypes.c_void_p(frames[0].data_ptr()), ctypes.c_void_p(out.data_ptr()), H, W,
+                                                   cptr, 3, 0.5, 0.5, 1.0))
+    torch.cuda.synchronize()
 
     def fence() -> None:
         ctx.sync()
@@ -140,7 +173,7 @@ def main() -> None:
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps * mp_per_frame / elapsed
     dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
-    alg_bytes = ALG_BYTES_PER_PX * H * W
+    alg_bytes = alg_bytes_per_px * H * W
     roofline = None
     traffic = None
     try:   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside the benchmark itself)
@@ -160,7 +193,7 @@ def main() -> None:
                     "note": "AHD is VALU-issue bound (VALU busy ~95 %, about 1.0k instructions/px vs 16 B/px); the HBM fraction is reported as required, not expected to approach 1"}
 
     cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and quality >= 0:
         try:
             from oracle import oracle
             sh = H // 2 - (H // 2) % 2            # bounded sample: the top half of frame 0 (about 10 s of CPU work for AHD)

@@ -374,7 +374,9 @@ int pysp_fuse_raw_dev(pysp_ctx* ctx, const float* const* d_frames, int K, int H,
     if (K < 1 || K > 16) return fail(PYSP_EBADARG, "fuse_raw: 1..16 exposures supported (got %d)", K);
     if (!even_dims(H, W) || kmax < 0 || kmax >= K) return fail(PYSP_EBADARG, "fuse_raw: bad shape %dx%d or kmax %d", H, W, kmax);
     ctx->tic();
+    ctx->tl.begin(ctx->stream, "k_fuse_raw");
     LAUNCH_TRY(launch_fuse_raw(ctx->stream, d_frames, K, H, W, ev_off, bias, kmax, d_out, d_count));
+    ctx->tl.end(ctx->stream);
     ctx->toc();
     return PYSP_OK;
 }
@@ -445,7 +447,9 @@ int pysp_warp_rectilinear_dev(pysp_ctx* ctx, const float* d_in, float* d_out, in
     if (!d_in || !d_out || !coeffs || d_in == d_out) return fail(PYSP_EBADARG, "warp_rectilinear: null or aliased buffers");
     if (planes != 3 || H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_rectilinear: plane count %d does not match a 3-channel image", planes);
     ctx->tic();
+    ctx->tl.begin(ctx->stream, "k_warp_remap");
     LAUNCH_TRY(launch_warp_remap(ctx->stream, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale, ctx->lanczos));
+    ctx->tl.end(ctx->stream);
     ctx->toc();
     return PYSP_OK;
 }

@@ -158,19 +158,28 @@ static WarpGeom warp_geom(int width, int height, float cxn, float cyn) {
     return g;
 }
 struct WarpCoef { float kr0, kr1, kr2, kr3, kt0, kt1; };
-DEVI void warp_px(float sx, float sy, const WarpCoef& k, const WarpGeom& g, float scale, float& ox, float& oy) {
-    float dx = (sx - g.cx) / g.m, dy = (sy - g.cy) / g.m;
-    float dx2 = dx * dx, dy2 = dy * dy;
-    float r = (float)sqrt((double)(dx2 + dy2));
+// channel-independent part of pyx:26-29 (dx, dy, r and its even powers) and the per-channel polynomial :30-40
+struct WarpRad { float dx, dy, dx2, dy2, r2, r4, r6; };
+DEVI WarpRad warp_rad(float sx, float sy, const WarpGeom& g) {
+    WarpRad w;
+    w.dx = (sx - g.cx) / g.m; w.dy = (sy - g.cy) / g.m;
+    w.dx2 = w.dx * w.dx; w.dy2 = w.dy * w.dy;
+    float r = sqrtf(w.dx2 + w.dy2);   // == float(sqrt(double(s))): the float64 sqrt rounded to float32 is the correctly rounded float32 sqrt
     double rd = (double)r, r2d = rd * rd;
-    float r2 = (float)r2d, r4 = (float)(r2d * r2d), r6 = (float)((r2d * r2d) * r2d);
-    float f = ((k.kr0 + (k.kr1 * r2)) + (k.kr2 * r4)) + (k.kr3 * r6);
-    float dxr = f * dx, dyr = f * dy;
-    float dxt = k.kt0 * ((2.0f * dx) * dy) + k.kt1 * (r2 + 2.0f * dx2);
-    float dyt = k.kt1 * ((2.0f * dx) * dy) + k.kt0 * (r2 + 2.0f * dy2);
+    w.r2 = (float)r2d; w.r4 = (float)(r2d * r2d); w.r6 = (float)((r2d * r2d) * r2d);
+    return w;
+}
+DEVI void warp_poly(float sx, float sy, const WarpRad& w, const WarpCoef& k, const WarpGeom& g, float scale, float& ox, float& oy) {
+    float f = ((k.kr0 + (k.kr1 * w.r2)) + (k.kr2 * w.r4)) + (k.kr3 * w.r6);
+    float dxr = f * w.dx, dyr = f * w.dy;
+    float dxt = k.kt0 * ((2.0f * w.dx) * w.dy) + k.kt1 * (w.r2 + 2.0f * w.dx2);
+    float dyt = k.kt1 * ((2.0f * w.dx) * w.dy) + k.kt0 * (w.r2 + 2.0f * w.dy2);
     float xp = g.cx + g.m * (dxr + dxt), yp = g.cy + g.m * (dyr + dyt);
     ox = sx + (xp - sx) * scale;
     oy = sy + (yp - sy) * scale;
+}
+DEVI void warp_px(float sx, float sy, const WarpCoef& k, const WarpGeom& g, float scale, float& ox, float& oy) {
+    warp_poly(sx, sy, warp_rad(sx, sy, g), k, g, scale, ox, oy);
 }
 __global__ void __launch_bounds__(256) k_warp_table(WarpCoef k, WarpGeom g, float scale, int width, int height,
                                                     const float* __restrict__ seed, float* __restrict__ table) {
@@ -221,43 +230,112 @@ struct RemapParams {
     WarpGeom g;
     float scale;
 };
+namespace {
+constexpr int WBX = 64, WBY = 8;            // output block of one workgroup (two rows per thread)
+constexpr int WTW = 96, WTH = 24;           // largest per-channel source tile staged in LDS: 3 x 9 KB
+}
+// One workgroup = 64x8 output pixels.  Each channel has its own smooth warp, so the 8x8 Lanczos footprints of
+// a block cover a small source rectangle per channel, bounded by the block's corner pixels (+2 cells): it is
+// staged in LDS once per channel (zero outside the image = BORDER_CONSTANT 0) and the 64 taps per pixel and
+// channel are conflict-free LDS reads.  A pixel whose footprint is not inside the staged rectangle (extreme
+// distortion) takes the same taps from global memory instead, so correctness never depends on the bound.
 __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     __shared__ float stab[256];
-    stab[threadIdx.x] = p.tab[threadIdx.x];
-    __syncthreads();
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= p.W || y >= p.H) return;
+    __shared__ float tile[3][WTH * WTW];
+    __shared__ int corner[3][4][2];          // per channel: source cell (ix, iy) of the block's four corner pixels
+    const int tid = threadIdx.x;
+    stab[tid] = p.tab[tid];
+    const int x = blockIdx.x * WBX + (tid & 63), y0 = blockIdx.y * WBY + (tid >> 6) * 2;
     const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
-    float res[3];
+    auto cell = [&](float mx, float my, int& fx, int& fy) {
+        mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);       // np.clip, chan_distortion_corr.py:95-96
+        my = my < 0.0f ? 0.0f : (my > ymax ? ymax : my);
+        fx = (int)rintf(mx * 32.0f); fy = (int)rintf(my * 32.0f);
+    };
+    if (tid < 12) {
+        const int c = tid >> 2, k = tid & 3;
+        int cx = min(blockIdx.x * WBX + ((k & 1) ? WBX - 1 : 0), p.W - 1), cy = min(blockIdx.y * WBY + ((k & 2) ? WBY - 1 : 0), p.H - 1);
+        float mx, my; int fx, fy;
+        warp_px((float)cx, (float)cy, p.k[c], p.g, p.scale, mx, my);
+        cell(mx, my, fx, fy);
+        corner[c][k][0] = fx >> 5; corner[c][k][1] = fy >> 5;
+    }
+    int sx[2][3], sy[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        WarpRad wr = warp_rad((float)x, (float)(y0 + j), p.g);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float mx, my;
+            warp_poly((float)x, (float)(y0 + j), wr, p.k[c], p.g, p.scale, mx, my);
+            cell(mx, my, sx[j][c], sy[j][c]);
+        }
+    }
+    __syncthreads();
+    int tx0[3], ty0[3], tw[3], th[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        float mx, my;
-        warp_px((float)x, (float)y, p.k[c], p.g, p.scale, mx, my);
-        mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);
-        my = my < 0.0f ? 0.0f : (my > ymax ? ymax : my);
-        int sx = (int)rintf(mx * 32.0f), sy = (int)rintf(my * 32.0f);
-        int ix = (sx >> 5) - 3, iy = (sy >> 5) - 3;
-        const float* wx = stab + 8 * (sx & 31);
-        const float* wy = stab + 8 * (sy & 31);
-        float sum = 0.0f;
-        for (int r = 0; r < 8; r++) {
-            int yy = iy + r;
-            bool yin = (unsigned)yy < (unsigned)p.H;
-            const float* row = p.in + ((size_t)(yin ? yy : 0) * p.W) * 3 + c;
-            float acc = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                int xx = ix + t;
-                float s = (yin && (unsigned)xx < (unsigned)p.W) ? row[(size_t)xx * 3] : 0.0f;
-                float v = s * (wy[r] * wx[t]);
-                acc = t == 0 ? v : acc + v;
-            }
-            sum = sum + acc;
+        int lox = min(min(corner[c][0][0], corner[c][1][0]), min(corner[c][2][0], corner[c][3][0]));
+        int loy = min(min(corner[c][0][1], corner[c][1][1]), min(corner[c][2][1], corner[c][3][1]));
+        int hix = max(max(corner[c][0][0], corner[c][1][0]), max(corner[c][2][0], corner[c][3][0]));
+        int hiy = max(max(corner[c][0][1], corner[c][1][1]), max(corner[c][2][1], corner[c][3][1]));
+        tx0[c] = lox - 3 - 2; ty0[c] = loy - 3 - 2;            // 2 cells of margin on every side
+        tw[c] = min(hix + 4 + 2 - tx0[c] + 1, WTW); th[c] = min(hiy + 4 + 2 - ty0[c] + 1, WTH);
+        const int n = tw[c] * th[c];
+        for (int idx = tid; idx < n; idx += 256) {
+            int ry = idx / tw[c], rx = idx - ry * tw[c];
+            int gx = tx0[c] + rx, gy = ty0[c] + ry;
+            float v = 0.0f;
+            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) v = p.in[((size_t)gy * p.W + gx) * 3 + c];
+            tile[c][ry * WTW + rx] = v;
         }
-        res[c] = sum;
     }
-    float* o = p.out + ((size_t)y * p.W + x) * 3;
-    o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+    __syncthreads();
+    if (x >= p.W) return;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int y = y0 + j;
+        if (y >= p.H) break;
+        float res[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int ix = (sx[j][c] >> 5) - 3, iy = (sy[j][c] >> 5) - 3;
+            const float* wx = stab + 8 * (sx[j][c] & 31);
+            const float* wy = stab + 8 * (sy[j][c] & 31);
+            float sum = 0.0f;
+            const int lx = ix - tx0[c], ly = iy - ty0[c];
+            if (lx >= 0 && ly >= 0 && lx + 8 <= tw[c] && ly + 8 <= th[c]) {
+                const float* t0 = &tile[c][ly * WTW + lx];
+                for (int r = 0; r < 8; r++) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        float v = t0[r * WTW + t] * (wy[r] * wx[t]);
+                        acc = t == 0 ? v : acc + v;
+                    }
+                    sum = sum + acc;
+                }
+            } else {
+                for (int r = 0; r < 8; r++) {
+                    int yy = iy + r;
+                    bool yin = (unsigned)yy < (unsigned)p.H;
+                    const float* row = p.in + ((size_t)(yin ? yy : 0) * p.W) * 3 + c;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        int xx = ix + t;
+                        float s = (yin && (unsigned)xx < (unsigned)p.W) ? row[(size_t)xx * 3] : 0.0f;
+                        float v = s * (wy[r] * wx[t]);
+                        acc = t == 0 ? v : acc + v;
+                    }
+                    sum = sum + acc;
+                }
+            }
+            res[c] = sum;
+        }
+        float* o = p.out + ((size_t)y * p.W + x) * 3;
+        o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
+    }
 }
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
                       double cyn, float scale, const float* d_lanczos_tab) {
@@ -269,7 +347,7 @@ int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, in
         p.k[c] = {(float)k[0], (float)k[1], (float)k[2], (float)k[3], (float)k[4], (float)k[5]};
     }
     p.g = warp_geom(W, H, (float)cxn, (float)cyn);
-    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    dim3 grid((W + WBX - 1) / WBX, (H + WBY - 1) / WBY);
     hipLaunchKernelGGL(k_warp_remap, grid, dim3(256), 0, st, p);
     return CHECK_LAUNCH();
 }
