@@ -48,6 +48,8 @@ def main() -> None:
     ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -57,15 +59,21 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     dist = None
+    n_dev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % n_dev                 # one rank per GPU; the modulo only matters for a gloo rehearsal on one GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
     else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")
 
     from pysp_amd import _lib
     from pysp_amd.colorize.transform import final_matrix
@@ -78,14 +86,14 @@ def main() -> None:
     from pysp_amd.multi_gpu import broadcast_params
     if rank == 0:
         wbobj = default_wb()
-        wb_np, M_np = broadcast_params(wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix()), src=0, device=dev)
+        wb_np, M_np = broadcast_params(wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix()), src=0, device=coll_dev)
     else:
-        wb_np, M_np = broadcast_params(np.zeros(3, np.float32), np.zeros((3, 3)), src=0, device=dev)
+        wb_np, M_np = broadcast_params(np.zeros(3, np.float32), np.zeros((3, 3)), src=0, device=coll_dev)
     p = np.concatenate([wb_np.astype(np.float64), M_np.reshape(-1)])
     wb = _lib.wb3(wb_np)
     M = _lib.mat9(M_np)
 
-    ctx = _lib.Context(local_rank)            # own HIP stream; kernels are timed with events on THAT stream
+    ctx = _lib.Context(dev_index)             # own HIP stream; kernels are timed with events on THAT stream
     L = _lib.lib()
     alg_bytes_per_px = ALG_BYTES_PER_PX
 
@@ -150,7 +158,7 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
