@@ -30,10 +30,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_PX = 16          # 4 B mosaic read + 12 B RGB written
 
 WORKLOADS = {
-    # name: (H, W, quality, stages, description)
+    # name: (H, W, quality, stages, description[, tail])   tail: 2 = to_lin_srgb + lin_srgb_to_srgb (default), 1 = to_lin_srgb only
     "ahd24": (4000, 6000, 2, 1, "24MP RGGB, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb"),
     "eag24": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + to_lin_srgb + lin_srgb_to_srgb"),
     "draft12": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + to_lin_srgb + lin_srgb_to_srgb"),
+    "eag24ccm": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + WB + 3x3 CCM (to_lin_srgb), BASELINE config 3 per frame", 1),
+    "eag24raw": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) only (RawDemosaicData.image)", 0),
     # secondary kernels (BASELINE configs 4 and 5), reported with their own algorithmic bytes
     "fuse45": (5464, 8192, -1, 0, "raw_hdr fuse_exposures_to_raw, 7 x 45MP exposures -> HDR mosaic + count (36 B per output px)"),
     "warp100": (8736, 11648, -2, 0, "100MP RGB, DNG WarpRectilinear per-channel Lanczos-4 remap (24 B/px)"),
@@ -79,7 +81,8 @@ def main() -> None:
     from pysp_amd.colorize.transform import final_matrix
     from pysp_amd.synth import default_wb, rggb_frame
 
-    H, W, quality, stages, desc = WORKLOADS[args.workload]
+    H, W, quality, stages, desc = WORKLOADS[args.workload][:5]
+    tail = WORKLOADS[args.workload][5] if len(WORKLOADS[args.workload]) > 5 else 2
     mp_per_frame = H * W / 1e6
 
     # ---- shared parameters: rank 0 owns them, everyone receives them over RCCL/xGMI (once per batch)
@@ -104,8 +107,8 @@ def main() -> None:
 
         def step(i: int) -> None:
             f = frames[i % len(frames)]
-            _lib.check(L.pysp_pipeline_srgb_dev(ctx.handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, 0,
-                                                ctypes.c_void_p(out.data_ptr())))
+            _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, tail,
+                                           ctypes.c_void_p(out.data_ptr())))
     elif quality == -1:
         K = 7
         base = rggb_frame(H, W, 1000 + rank, scale=8.0, clip_hi=False)

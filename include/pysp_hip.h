@@ -104,6 +104,10 @@ int pysp_wb_scale_f32(pysp_ctx *ctx, const float *in, size_t npx, const float co
 int pysp_pipeline_srgb_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *srgb);
 int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *d_srgb);
 
+/* General form: tail 0 = pysp_demosaic_dev, 1 = + to_lin_srgb (clip + CCM; BASELINE config 3 "debayer + WB + CCM"),
+ * 2 = pysp_pipeline_srgb_dev, 3 = with x/(1+x) in between. */
+int pysp_pipeline_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *d_out);
+
 /* The same pipelines fed by the raw uint16 mosaic: normalization.py:4-24 (clip(x-black_c,0,sat_c)/sat_c, CFA
  * sites indexed r,g1,b,g2) is fused into the tile loader, so the float32 mosaic never exists in memory
  * (image.py:229 followed by :156-183).  tail: 0 camera RGB (RawDemosaicData.image), 1 to_lin_srgb,

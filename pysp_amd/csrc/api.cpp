@@ -297,6 +297,12 @@ int pysp_pipeline_srgb_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, co
     return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, reinhard ? 3 : 2, d_srgb);
 }
 
+int pysp_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages,
+                      int tail, float* d_out) {
+    CTX_ENTER(ctx);
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline: tail must be 0..3");
+    return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, tail, d_out);
+}
 int pysp_pipeline_u16_dev(pysp_ctx* ctx, const uint16_t* d_bayer, int H, int W, const float black[4], const float sat[4], const float wb[3],
                           const double M[9], int quality, int hdr, int stages, int tail, float* d_out) {
     CTX_ENTER(ctx);
