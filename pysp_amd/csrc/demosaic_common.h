@@ -23,6 +23,18 @@ DEVI float load_mosaic(const MosaicSrc& m, size_t idx, int site) {
     }
     return m.f32[idx];
 }
+// Two horizontally adjacent mosaic samples (even column first) as one 8-byte (f32) / 4-byte (u16) load.
+template <bool U16>
+DEVI float2 load_mosaic_pair(const MosaicSrc& m, size_t idx, int site_even, int site_odd) {
+    if (U16) {
+        ushort2 raw = *reinterpret_cast<const ushort2*>(m.u16 + idx);
+        float a = (float)raw.x - m.black[site_even], b = (float)raw.y - m.black[site_odd];
+        a = a < 0.0f ? 0.0f : (a > m.sat[site_even] ? m.sat[site_even] : a);
+        b = b < 0.0f ? 0.0f : (b > m.sat[site_odd] ? m.sat[site_odd] : b);
+        return make_float2(a / m.sat[site_even], b / m.sat[site_odd]);
+    }
+    return *reinterpret_cast<const float2*>(m.f32 + idx);
+}
 
 struct Win3 { float v[3][3]; };
 

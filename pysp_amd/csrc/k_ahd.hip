@@ -141,16 +141,30 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     const int tq0x = blockIdx.x * TQX, tq0y = blockIdx.y * TQY;
     const double* M = p.ccm.m;
 
-    // ---- P0: white-balanced mosaic planes, symmetric (edge-duplicating) reflect per plane (ahd.py:77-80)
-    for (int idx = tid; idx < 4 * MWY * MWX; idx += NT_A) {
-        int ry = idx / (2 * MWX), rx = idx - ry * (2 * MWX);
-        int my = ry >> 1, mx = rx >> 1, dy = ry & 1, dx = rx & 1;
-        int qi = TINY ? b_sym(tq0y - 3 + my, h) : b_sym1(tq0y - 3 + my, h);
-        int qj = TINY ? b_sym(tq0x - 3 + mx, w) : b_sym1(tq0x - 3 + mx, w);
-        int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
-        float wbv = plane == P_R ? p.wb[0] : (plane == P_B ? p.wb[2] : p.wb[1]);
-        int site = dy ? (dx ? 2 : 3) : (dx ? 1 : 0);   // r,g1,b,g2
-        mw[(plane * MWY + my) * MWX + mx] = load_mosaic<U16>(p.src, (size_t)(2 * qi + dy) * W + (2 * qj + dx), site) * wbv;
+    // ---- P0: white-balanced mosaic planes, symmetric (edge-duplicating) reflect per plane (ahd.py:77-80).
+    // One 8-byte load per quad row; a thread's loads are all issued before its first LDS store.
+    {
+        constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT_A - 1) / NT_A;
+        float2 tmp[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int idx = tid + k * NT_A;
+            if (idx >= NPAIR) idx = NPAIR - 1;
+            int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
+            int qi = TINY ? b_sym(tq0y - 3 + my, h) : b_sym1(tq0y - 3 + my, h);
+            int qj = TINY ? b_sym(tq0x - 3 + mx, w) : b_sym1(tq0x - 3 + mx, w);
+            tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int idx = tid + k * NT_A;
+            if (idx < NPAIR) {
+                int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
+                // even row: (R, G1) ; odd row: (G2, B)
+                mw[((dy ? P_G2 : P_R) * MWY + my) * MWX + mx] = tmp[k].x * (dy ? p.wb[1] : p.wb[0]);
+                mw[((dy ? P_B : P_G1) * MWY + my) * MWX + mx] = tmp[k].y * (dy ? p.wb[2] : p.wb[1]);
+            }
+        }
     }
     __syncthreads();
 
@@ -391,12 +405,26 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
     const int tid = threadIdx.x, H = p.H, W = p.W;
     const int tx0 = blockIdx.x * BTX, ty0 = blockIdx.y * BTY;
 
-    for (int idx = tid; idx < B4Y * B4X; idx += NT_B) {
-        int ly = idx / B4X, lx = idx - ly * B4X;
-        int y = b_rep(ty0 - 4 + ly, H), x = b_rep(tx0 - 4 + lx, W);
-        const float* s = p.in + ((size_t)y * W + x) * 3;
-        float r = s[0], g = s[1], b = s[2];
-        s_g[ly][lx] = g; s_drg[ly][lx] = r - g; s_dbg[ly][lx] = b - g;
+    {   // all global loads of a thread are issued before its first LDS store (they are in flight together)
+        constexpr int NL = (B4Y * B4X + NT_B - 1) / NT_B;
+        float tr[NL], tg[NL], tb[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int idx = tid + k * NT_B;
+            if (idx >= B4Y * B4X) idx = B4Y * B4X - 1;
+            int ly = idx / B4X, lx = idx - ly * B4X;
+            int y = b_rep(ty0 - 4 + ly, H), x = b_rep(tx0 - 4 + lx, W);
+            const float* s = p.in + ((size_t)y * W + x) * 3;
+            tr[k] = s[0]; tg[k] = s[1]; tb[k] = s[2];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int idx = tid + k * NT_B;
+            if (idx < B4Y * B4X) {
+                int ly = idx / B4X, lx = idx - ly * B4X;
+                s_g[ly][lx] = tg[k]; s_drg[ly][lx] = tr[k] - tg[k]; s_dbg[ly][lx] = tb[k] - tg[k];
+            }
+        }
     }
     __syncthreads();
     // r', b' and the second-level differences on the halo-2 region, two horizontally adjacent pixels per

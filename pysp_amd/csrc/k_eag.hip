@@ -50,15 +50,29 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
     const int tq0x = blockIdx.x * TQX, tq0y = blockIdx.y * TQY;
 
-    // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87)
-    for (int idx = tid; idx < 4 * MWY * MWX; idx += NT) {
-        int ry = idx / (2 * MWX), rx = idx - ry * (2 * MWX);
-        int my = ry >> 1, mx = rx >> 1, dy = ry & 1, dx = rx & 1;
-        int qi = TINY ? b_sym(tq0y - 2 + my, h) : b_sym1(tq0y - 2 + my, h);
-        int qj = TINY ? b_sym(tq0x - 2 + mx, w) : b_sym1(tq0x - 2 + mx, w);
-        int plane = dy ? (dx ? P_B : P_G2) : (dx ? P_G1 : P_R);
-        int site = dy ? (dx ? 2 : 3) : (dx ? 1 : 0);   // r,g1,b,g2
-        mw[plane][my][mx] = load_mosaic<U16>(p.src, (size_t)(2 * qi + dy) * W + (2 * qj + dx), site);
+    // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87).  One 8-byte load per quad
+    // row; all loads of a thread are issued before the first LDS store so that they are in flight together.
+    {
+        constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT - 1) / NT;
+        float2 tmp[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int idx = tid + k * NT;
+            if (idx >= NPAIR) idx = NPAIR - 1;
+            int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
+            int qi = TINY ? b_sym(tq0y - 2 + my, h) : b_sym1(tq0y - 2 + my, h);
+            int qj = TINY ? b_sym(tq0x - 2 + mx, w) : b_sym1(tq0x - 2 + mx, w);
+            tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            int idx = tid + k * NT;
+            if (idx < NPAIR) {
+                int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
+                mw[dy ? P_G2 : P_R][my][mx] = tmp[k].x;
+                mw[dy ? P_B : P_G1][my][mx] = tmp[k].y;
+            }
+        }
     }
     __syncthreads();
 
