@@ -422,3 +422,65 @@ def test_uint16_fused_loader(orc, wbobj):
     pipe.sync()
     norm = orc.bayer_normalize(raw, black, sat)
     assert np.array_equal(out.cpu().numpy(), orc.cam_to_rgb(orc.demosaic_ahd(norm, wb, M, False, 1), M, True))
+
+
+# ---- BASELINE configs 4 and 5 at their full sizes: size-independent properties -------------------------------------------
+def test_full_size_45mp_hdr_stack(orc, wbobj):
+    """7 x 45 MP exposures (8192x5464) fused on the device, AHD(HDR) + Reinhard + sRGB; crops of the fused
+    mosaic and of the final image are checked against the oracle, the whole frame for sanity."""
+    import torch
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    pipe = DevicePipeline(0)
+    wb, M = _wbM(orc)
+    H, W, K = 5464, 8192, 7
+    base = rggb_frame(H, W, 1004, scale=8.0, clip_hi=False)
+    evs = [10.0 + k for k in range(K)]
+    frames = [torch.from_numpy(np.clip(base * np.float32(2.0 ** -k), 0, 1)).cuda() for k in range(K)]
+    fused, cnt, target, lim = pipe.fuse_raw(frames, evs, wb)
+    out, _ = pipe.hdr_stack_to_srgb(frames, evs, wbobj)
+    pipe.sync()
+    fused_h = fused.cpu().numpy()
+    assert target == 13.0 and lim == 8.0 and int(cnt.max()) <= K and int(cnt.min()) >= 0
+    for (y0, x0, h, w) in ((0, 0, 200, 320), (2700, 4000, 220, 300), (H - 200, W - 320, 200, 320)):
+        crops = [np.ascontiguousarray(np.clip(base[y0:y0 + h, x0:x0 + w] * np.float32(2.0 ** -k), 0, 1)) for k in range(K)]
+        ref, refc, _, _ = orc.fuse_raw(crops, evs, wb)
+        assert np.array_equal(fused_h[y0:y0 + h, x0:x0 + w], ref)             # pointwise: crops are exact
+        assert np.array_equal(cnt[y0:y0 + h, x0:x0 + w].cpu().numpy(), refc)
+        # final image: interior of the crop (16 px margin unless the crop touches the true border)
+        ref_srgb = orc.pipeline_srgb(np.ascontiguousarray(fused_h[y0:y0 + h, x0:x0 + w]), wb, M, 2, True, 1, True)
+        ys = slice(0 if y0 == 0 else 16, h if y0 + h == H else h - 16)
+        xs = slice(0 if x0 == 0 else 16, w if x0 + w == W else w - 16)
+        u = ulp_diff(out[y0:y0 + h, x0:x0 + w].cpu().numpy()[ys, xs], ref_srgb[ys, xs])
+        assert u.max() <= 1 and np.mean(u != 0) < 1e-4
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all() and o.min() >= 0 and o.max() <= 1
+
+
+def test_full_size_100mp_ahd3_warp(orc, wbobj):
+    """100 MP medium-format frame (11648x8736): AHD(postprocess_stages=3), then WarpRectilinear; crops vs the oracle."""
+    import torch
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    pipe = DevicePipeline(0)
+    wb, M = _wbM(orc)
+    H, W = 8736, 11648
+    bay = rggb_frame(H, W, 1005)
+    rgb = pipe.demosaic(torch.from_numpy(bay).cuda(), wb, M, stages=3)
+    pipe.sync()
+    for (y0, x0, h, w) in ((0, 0, 240, 300), (4000, 6002, 256, 300), (H - 240, W - 300, 240, 300)):
+        ref = orc.demosaic_ahd(np.ascontiguousarray(bay[y0:y0 + h, x0:x0 + w]), wb, M, False, 3)
+        ys = slice(0 if y0 == 0 else 24, h if y0 + h == H else h - 24)      # 7 + 4*3 rows of dependency, rounded up
+        xs = slice(0 if x0 == 0 else 24, w if x0 + w == W else w - 24)
+        assert np.array_equal(rgb[y0:y0 + h, x0:x0 + w].cpu().numpy()[ys, xs], ref[ys, xs]), (y0, x0)
+    # identity warp reproduces the image, a real one keeps values finite and is almost the identity at the centre
+    ident = np.array([[1.0, 0, 0, 0, 0, 0]] * 3)
+    same = pipe.warp(rgb, ident, (0.5, 0.5))
+    pipe.sync()
+    assert float((same != rgb).float().mean()) < 1e-3
+    coeffs = np.array([[1.0, 0.01, 0.002, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0, 0.0], [1.0, -0.01, 0.002, 0.0, 0.0, 0.0]])
+    warped = pipe.warp(rgb, coeffs, (0.5, 0.5))
+    pipe.sync()
+    assert bool(torch.isfinite(warped).all())
+    cy, cx = H // 2, W // 2
+    assert float((warped[cy - 8:cy + 8, cx - 8:cx + 8] - rgb[cy - 8:cy + 8, cx - 8:cx + 8]).abs().max()) < 0.05
