@@ -70,6 +70,14 @@ int pysp_rgbg_to_bayer_f32(pysp_ctx *ctx, const float *r, const float *g1, const
 /* normalization.py:4-24 bayer_normalize; black/sat indexed r,g1,b,g2 */
 int pysp_bayer_normalize_u16(pysp_ctx *ctx, const uint16_t *bayer, int H, int W, const float black[4], const float sat[4], float *out);
 
+/* ---- pre-demosaic cleanup (the step before the path) -----------------------------------------
+ * raw_bad_pixel_corr.py:30-65 find_erroneous_pixels_threshold: four (H/2,W/2) uint8 masks (1 = hot) for the
+ * r,g1,b,g2 planes. */
+int pysp_find_hot_pixels_f32(pysp_ctx *ctx, const float *bayer, int H, int W, float min_delta, int min_neighbour_count, uint8_t *mask_r, uint8_t *mask_g1, uint8_t *mask_b, uint8_t *mask_g2);
+/* raw_correction.py:25-62 flat_frame_correction on mosaics; mean[4] = np.mean of the flat's r,g1,b,g2 planes
+ * (:44, computed by the caller with NumPy so that the float32 pairwise-summation order is NumPy's). */
+int pysp_flat_field_f32(pysp_ctx *ctx, const float *bayer, const float *flat, int H, int W, const float mean[4], int clamp_high, float *out);
+
 /* ---- AHD homogeneity vote -------------------------------------------------------------------
  * debayer/ahd_homogeneity_cython.pyx:61-68  build_map(lab, k_pad, domain_k, is_vertical)
  * lab: (Hp,Wp,3) already padded by k_pad; out: (Hp-2k_pad, Wp-2k_pad) float32 counts.

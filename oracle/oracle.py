@@ -344,6 +344,28 @@ def fuse_rgb(images: Sequence[np.ndarray], evs: Sequence[float], coeffs, M=None,
     return out, cnt, outs
 
 
+def find_hot_threshold(bayer, min_delta: float = 0.025, min_neighbour_count: int = 5):
+    b = _f32(bayer); H, W = b.shape
+    masks = [np.empty((H // 2, W // 2), np.uint8) for _ in range(4)]
+    _chk(lib().orc_find_hot_threshold(_p(b), H, W, ctypes.c_float(min_delta), int(min_neighbour_count),
+                                      *[_p(m, ctypes.c_uint8) for m in masks]), "find_hot_threshold")
+    return [m.astype(bool) for m in masks]
+
+
+def plane_views(bayer: np.ndarray):
+    """The four strided views bayer_chan_mixer.py:4-21 returns (r, g1, b, g2)."""
+    evens = bayer[0::2, :].astype(np.float32); odds = bayer[1::2, :].astype(np.float32)
+    return evens[:, 0::2], evens[:, 1::2], odds[:, 1::2], odds[:, 0::2]
+
+
+def flat_field(bayer, flat, clamp_high: bool = False) -> np.ndarray:
+    b, f = _f32(bayer), _f32(flat); H, W = b.shape
+    mean = np.array([np.mean(p) for p in plane_views(f)], dtype=np.float32)      # raw_correction.py:44
+    out = np.empty_like(b)
+    _chk(lib().orc_flat_field(_p(b), _p(f), H, W, _p(mean), int(bool(clamp_high)), _p(out)), "flat_field")
+    return out
+
+
 def warp_table(kr0, kr1, kr2, kr3, kt0, kt1, width, height, cxn, cyn, scale, seed=None) -> np.ndarray:
     out = np.empty((height, width, 2), np.float32)
     sp = None

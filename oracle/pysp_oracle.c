@@ -957,6 +957,65 @@ int orc_warp_rectilinear(float *image, int H, int W, const double *coeffs, int p
     return ORC_OK;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * raw_bad_pixel_corr.py:30-65 find_erroneous_pixels_threshold: per CFA plane, np.pad(..., mode="reflect")
+ * (= REFLECT_101), eight neighbours, hot where more than min_neighbour_count of them are below
+ * (chan - min_delta) (float32 subtraction, python-float weak scalar).  masks: four (h,w) uint8 planes r,g1,b,g2. */
+int orc_find_hot_threshold(const float *bayer, int H, int W, float min_delta, int min_count, uint8_t *mr, uint8_t *mg1,
+                           uint8_t *mb, uint8_t *mg2) {
+    if (H < 2 || W < 2 || (H & 1) || (W & 1)) return ORC_EBADARG;
+    int h = H / 2, w = W / 2;
+    uint8_t *masks[4] = {mr, mg1, mb, mg2};
+    static const int oy[4] = {0, 0, 1, 1}, ox[4] = {0, 1, 1, 0};   /* r, g1, b, g2 */
+#pragma omp parallel for
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++)
+            for (int pl = 0; pl < 4; pl++) {
+                float c = bayer[(size_t)(2 * i + oy[pl]) * W + 2 * j + ox[pl]] - min_delta;
+                int cnt = 0;
+                for (int di = -1; di <= 1; di++)
+                    for (int dj = -1; dj <= 1; dj++) {
+                        if (!di && !dj) continue;
+                        int ii = b_101(i + di, h), jj = b_101(j + dj, w);
+                        if (c > bayer[(size_t)(2 * ii + oy[pl]) * W + 2 * jj + ox[pl]]) cnt++;
+                    }
+                masks[pl][(size_t)i * w + j] = cnt > min_count;
+            }
+    return ORC_OK;
+}
+
+/* raw_correction.py:25-62 flat_frame_correction, per CFA plane (correct_channel :42-58):
+ *   out = (chan * mean_flat) / flat ; if every value is inf: out = chan ; +inf -> max of the finite values ;
+ *   negative -> 0 ; clamp_high: > 1 -> 1.  mean[4] = np.mean of the four flat planes, computed by the caller
+ *   with NumPy on identically strided views (float32 pairwise summation order is NumPy's). */
+int orc_flat_field(const float *bayer, const float *flat, int H, int W, const float mean[4], int clamp_high, float *out) {
+    if (H < 2 || W < 2 || (H & 1) || (W & 1)) return ORC_EBADARG;
+    static const int oy[4] = {0, 0, 1, 1}, ox[4] = {0, 1, 1, 0};
+    int h = H / 2, w = W / 2;
+    for (int pl = 0; pl < 4; pl++) {
+        float maxfin = -INFINITY; int all_inf = 1;
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                size_t o = (size_t)(2 * i + oy[pl]) * W + 2 * j + ox[pl];
+                float v = (bayer[o] * mean[pl]) / flat[o];
+                out[o] = v;
+                if (!isinf(v)) all_inf = 0;
+                if (isfinite(v) && v > maxfin) maxfin = v;
+            }
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                size_t o = (size_t)(2 * i + oy[pl]) * W + 2 * j + ox[pl];
+                float v = out[o];
+                if (all_inf) { out[o] = bayer[o]; continue; }
+                if (v == INFINITY) v = maxfin;
+                if (v < 0.0f) v = 0.0f;
+                if (clamp_high && v > 1.0f) v = 1.0f;
+                out[o] = v;
+            }
+    }
+    return ORC_OK;
+}
+
 #ifdef _OPENMP
 #include <omp.h>
 int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }

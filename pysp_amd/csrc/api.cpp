@@ -236,6 +236,37 @@ int pysp_build_map_f32(pysp_ctx* ctx, const float* lab, int Hp, int Wp, int k_pa
     return pysp_ctx_sync(ctx);
 }
 
+// ---- pre-demosaic cleanup -------------------------------------------------------------------------------
+int pysp_find_hot_pixels_f32(pysp_ctx* ctx, const float* bayer, int H, int W, float min_delta, int min_neighbour_count, uint8_t* mask_r,
+                             uint8_t* mask_g1, uint8_t* mask_b, uint8_t* mask_g2) {
+    CTX_ENTER(ctx);
+    if (!bayer || !mask_r || !mask_g1 || !mask_b || !mask_g2 || !even_dims(H, W)) return fail(PYSP_EBADARG, "find_hot_pixels: need even H,W >= 2 and non-null buffers");
+    size_t N = (size_t)H * W, n = N / 4;
+    float* d_in; uint8_t* d_m[4];
+    RESERVE(ctx, S_IN, N * 4, d_in);
+    for (int i = 0; i < 4; i++) RESERVE(ctx, S_P0 + i, n, d_m[i]);
+    TRY(h2d(ctx, d_in, bayer, N * 4));
+    ctx->tic();
+    LAUNCH_TRY(launch_hot_threshold(ctx->stream, d_in, H, W, min_delta, min_neighbour_count, d_m[0], d_m[1], d_m[2], d_m[3]));
+    ctx->toc();
+    uint8_t* outs[4] = {mask_r, mask_g1, mask_b, mask_g2};
+    for (int i = 0; i < 4; i++) TRY(d2h(ctx, outs[i], d_m[i], n));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_flat_field_f32(pysp_ctx* ctx, const float* bayer, const float* flat, int H, int W, const float mean[4], int clamp_high, float* out) {
+    CTX_ENTER(ctx);
+    if (!bayer || !flat || !mean || !out || !even_dims(H, W)) return fail(PYSP_EBADARG, "flat_field: need even H,W >= 2 and non-null buffers");
+    size_t N = (size_t)H * W;
+    float *d_in, *d_flat, *d_out; unsigned* d_stats;
+    RESERVE(ctx, S_IN, N * 4, d_in); RESERVE(ctx, S_TMP0, N * 4, d_flat); RESERVE(ctx, S_OUT, N * 4, d_out); RESERVE(ctx, S_AUX, 64, d_stats);
+    TRY(h2d(ctx, d_in, bayer, N * 4)); TRY(h2d(ctx, d_flat, flat, N * 4));
+    ctx->tic();
+    LAUNCH_TRY(launch_flat_field(ctx->stream, d_in, d_flat, H, W, mean, clamp_high != 0, d_out, d_stats));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, N * 4));
+    return pysp_ctx_sync(ctx);
+}
+
 // ---- demosaic / fused pipeline ----------------------------------------------------------------------
 static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
                             int stages, int tail, float* d_out) {

@@ -110,6 +110,84 @@ int launch_build_map(hipStream_t st, const float* lab, int Hp, int Wp, int k_pad
     return CHECK_LAUNCH();
 }
 
+// ---- pre-demosaic cleanup ----------------------------------------------------
+// raw_bad_pixel_corr.py:30-65 find_erroneous_pixels_threshold: one thread per mosaic pixel; the eight
+// same-colour neighbours sit 2 px away; np.pad(mode="reflect") = REFLECT_101 on the quarter plane.
+__global__ void __launch_bounds__(256) k_hot_threshold(const float* __restrict__ bayer, int H, int W, float min_delta, int min_count,
+                                                       uint8_t* mr, uint8_t* mg1, uint8_t* mb, uint8_t* mg2) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int h = H >> 1, w = W >> 1, i = y >> 1, j = x >> 1, oy = y & 1, ox = x & 1;
+    float c = bayer[(size_t)y * W + x] - min_delta;
+    int cnt = 0;
+#pragma unroll
+    for (int di = -1; di <= 1; di++)
+#pragma unroll
+        for (int dj = -1; dj <= 1; dj++) {
+            if (!di && !dj) continue;
+            int ii = b_101(i + di, h), jj = b_101(j + dj, w);
+            cnt += c > bayer[(size_t)(2 * ii + oy) * W + 2 * jj + ox] ? 1 : 0;
+        }
+    uint8_t* m = oy ? (ox ? mb : mg2) : (ox ? mg1 : mr);
+    m[(size_t)i * w + j] = cnt > min_count ? 1 : 0;
+}
+int launch_hot_threshold(hipStream_t st, const float* bayer, int H, int W, float min_delta, int min_count, uint8_t* mr, uint8_t* mg1,
+                         uint8_t* mb, uint8_t* mg2) {
+    dim3 g((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_hot_threshold, g, dim3(256), 0, st, bayer, H, W, min_delta, min_count, mr, mg1, mb, mg2);
+    return CHECK_LAUNCH();
+}
+
+// raw_correction.py:25-62 flat_frame_correction.  Pass 1: out = (x * mean_c) / flat, per-plane maximum of the
+// finite values (as an order-preserving unsigned key) and a count of non-infinite values.  Pass 2: per plane,
+// all-infinite -> leave the image alone; +inf -> that maximum; negative -> 0; optional clamp at 1.
+struct FlatMeans { float m[4]; };
+DEVI unsigned fkey(float f) { unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+DEVI float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__global__ void __launch_bounds__(256) k_flat_pass1(const float* __restrict__ bayer, const float* __restrict__ flat, int H, int W,
+                                                    FlatMeans mean, float* __restrict__ out, unsigned* stats /* [4][2]: max key, #non-inf */) {
+    __shared__ unsigned smax[2], scnt[2];
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (threadIdx.x < 2) { smax[threadIdx.x] = 0u; scnt[threadIdx.x] = 0u; }
+    __syncthreads();
+    if (x < W) {
+        int site = (y & 1) ? ((x & 1) ? 2 : 3) : ((x & 1) ? 1 : 0);
+        size_t o = (size_t)y * W + x;
+        float v = (bayer[o] * mean.m[site]) / flat[o];
+        out[o] = v;
+        if (!isinf(v)) atomicAdd(&scnt[x & 1], 1u);
+        if (isfinite(v)) atomicMax(&smax[x & 1], fkey(v));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        int site = (y & 1) ? (threadIdx.x ? 2 : 3) : (threadIdx.x ? 1 : 0);
+        if (scnt[threadIdx.x]) atomicAdd(&stats[site * 2 + 1], scnt[threadIdx.x]);
+        if (smax[threadIdx.x]) atomicMax(&stats[site * 2], smax[threadIdx.x]);
+    }
+}
+__global__ void __launch_bounds__(256) k_flat_pass2(const float* __restrict__ bayer, int H, int W, int clamp_high, float* __restrict__ out,
+                                                    const unsigned* __restrict__ stats) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    int site = (y & 1) ? ((x & 1) ? 2 : 3) : ((x & 1) ? 1 : 0);
+    size_t o = (size_t)y * W + x;
+    if (stats[site * 2 + 1] == 0u) { out[o] = bayer[o]; return; }          // np.isinf(output).all()
+    float v = out[o];
+    if (v == INFINITY) v = stats[site * 2] ? fkey_inv(stats[site * 2]) : v;
+    if (v < 0.0f) v = 0.0f;
+    if (clamp_high && v > 1.0f) v = 1.0f;
+    out[o] = v;
+}
+int launch_flat_field(hipStream_t st, const float* bayer, const float* flat, int H, int W, const float mean[4], int clamp_high, float* out,
+                      unsigned* d_stats8) {
+    if (hipMemsetAsync(d_stats8, 0, 8 * sizeof(unsigned), st) != hipSuccess) return -3;
+    FlatMeans m; for (int i = 0; i < 4; i++) m.m[i] = mean[i];
+    dim3 g((W + 255) / 256, H);
+    hipLaunchKernelGGL(k_flat_pass1, g, dim3(256), 0, st, bayer, flat, H, W, m, out, d_stats8);
+    hipLaunchKernelGGL(k_flat_pass2, g, dim3(256), 0, st, bayer, H, W, clamp_high, out, d_stats8);
+    return CHECK_LAUNCH();
+}
+
 // ---- pointwise colour ---------------------------------------------------------------------------
 // Four RGB pixels (three float4) per thread: 48 contiguous bytes in, 48 out.
 template <typename F>

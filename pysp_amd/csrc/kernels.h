@@ -26,6 +26,8 @@ int launch_demux_u16(hipStream_t st, const uint16_t* bayer, int H, int W, float*
 int launch_remux_f32(hipStream_t st, const float* r, const float* g1, const float* b, const float* g2, int h, int w, float* bayer);
 int launch_normalize_u16(hipStream_t st, const uint16_t* bayer, int H, int W, const float black[4], const float sat[4], float* out);
 int launch_build_map(hipStream_t st, const float* lab, int Hp, int Wp, int k_pad, int is_vertical, float* out);
+int launch_hot_threshold(hipStream_t st, const float* bayer, int H, int W, float min_delta, int min_count, uint8_t* mr, uint8_t* mg1, uint8_t* mb, uint8_t* mg2);
+int launch_flat_field(hipStream_t st, const float* bayer, const float* flat, int H, int W, const float mean[4], int clamp_high, float* out, unsigned* d_stats8);
 int launch_cam_to_rgb(hipStream_t st, const float* in, size_t npx, const double M[9], int clip, float* out);
 int launch_gamma(hipStream_t st, const float* in, size_t n, int decode, float* out);
 int launch_wb_scale(hipStream_t st, const float* in, size_t npx, const float coeff[3], int undo, float* out);

@@ -275,6 +275,32 @@ def main():
         save("g9_fuse_debayer", {"ref": "raw_hdr.py:7-83", "io_stubs": True, "colour_shim": True, "evs": evs},
              rgb=rgb_in, mult=MULT, xyz2cam=XYZ2CAM[0], white_xyz=oracle.xy_to_XYZ(WHITES_XY[0]), fused=fused_rgb, count=cnt_rgb)
 
+        # ---- G11 pre-demosaic cleanup: hot-pixel threshold detector and flat-field correction
+        from pySP.raw_bad_pixel_corr import find_erroneous_pixels_threshold
+        from pySP.raw_correction import flat_frame_correction
+        bay = np.clip(scene(20, 28, 31), 0, 1)
+        hot = bay.copy()
+        for (yy, xx) in ((0, 0), (5, 9), (10, 3), (19, 27), (7, 7), (12, 20)):
+            hot[yy, xx] = min(1.0, hot[yy, xx] + 0.4)
+        rb = RawBayerData(); rb.sensor_scaled = hot
+        masks = find_erroneous_pixels_threshold(rb)
+        masks2 = find_erroneous_pixels_threshold(rb, min_delta=0.01, min_neighbour_count=3)
+        yy, xx = np.mgrid[0:20, 0:28]
+        flat = (0.9 - 0.5 * ((yy - 10) ** 2 + (xx - 14) ** 2) / 400.0).astype(np.float32)
+        flat[3, 4] = 0.0            # division by zero -> +inf -> replaced by the channel maximum
+        flat[8, 9] = -0.2           # negative result -> clamped to zero
+        img = RawBayerData(); img.sensor_scaled = bay.copy()
+        fl = RawBayerData(); fl.sensor_scaled = flat
+        flat_frame_correction(img, fl)
+        img2 = RawBayerData(); img2.sensor_scaled = bay.copy()
+        flat_frame_correction(img2, fl, clamp_high=True)
+        img3 = RawBayerData(); img3.sensor_scaled = bay.copy()
+        zero = RawBayerData(); zero.sensor_scaled = np.zeros_like(flat)
+        flat_frame_correction(img3, zero)
+        save("g11_cleanup", {"ref": "raw_bad_pixel_corr.py:30-65, raw_correction.py:25-62", "io_stubs": True, "cv2_restated": True},
+             hot=hot, **{f"mask{i}": m for i, m in enumerate(masks)}, **{f"maskb{i}": m for i, m in enumerate(masks2)},
+             bayer=bay, flat=flat, corrected=img.sensor_scaled, corrected_clamped=img2.sensor_scaled, corrected_zero_flat=img3.sensor_scaled)
+
         # ---- G10 WarpRectilinear opcode list through apply_opcode_3_warp
         img = rng.random((20, 26, 3), dtype=np.float32)
         coeffs = [(1.0, 0.01, 0.002, 0.0, 0.0, 0.0), (1.0, 0.0, 0.0, 0.0, 0.0, 0.0), (1.0, -0.01, 0.002, 0.0, 0.0005, -0.0003)]

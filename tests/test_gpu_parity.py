@@ -484,3 +484,41 @@ def test_full_size_100mp_ahd3_warp(orc, wbobj):
     assert bool(torch.isfinite(warped).all())
     cy, cx = H // 2, W // 2
     assert float((warped[cy - 8:cy + 8, cx - 8:cx + 8] - rgb[cy - 8:cy + 8, cx - 8:cx + 8]).abs().max()) < 0.05
+
+
+# ---- the step before the path ---------------------------------------------------------------------------
+def test_hot_pixel_threshold_and_flat_field(orc):
+    from pysp_amd.image import RawBayerData
+    from pysp_amd.raw_bad_pixel_corr import find_erroneous_pixels_threshold, find_shared_pixels
+    from pysp_amd.raw_correction import flat_frame_correction
+    from pysp_amd.synth import rggb_frame
+    d, _ = load_golden("g11_cleanup")
+
+    def raw(a):
+        r = RawBayerData(); r.sensor_scaled = a
+        return r
+    masks = find_erroneous_pixels_threshold(raw(d["hot"]))
+    assert all(m.dtype == np.bool_ and np.array_equal(m, d[f"mask{i}"]) for i, m in enumerate(masks))
+    masks_b = find_erroneous_pixels_threshold(raw(d["hot"]), min_delta=0.01, min_neighbour_count=3)
+    assert all(np.array_equal(m, d[f"maskb{i}"]) for i, m in enumerate(masks_b))
+    shared = find_shared_pixels([masks, masks_b, masks], min_ratio=0.6)
+    assert all(np.array_equal(s, a & b) for s, a, b in zip(shared, masks, masks_b))      # 2 of 3 needed
+    for key, clamp in (("corrected", False), ("corrected_clamped", True)):
+        img = raw(d["bayer"].copy())
+        flat_frame_correction(img, raw(d["flat"]), clamp_high=clamp)
+        assert np.array_equal(img.sensor_scaled, d[key], equal_nan=True)
+    img = raw(d["bayer"].copy())
+    flat_frame_correction(img, raw(np.zeros_like(d["flat"])))
+    assert np.array_equal(img.sensor_scaled, d["corrected_zero_flat"], equal_nan=True)
+    # larger, against the oracle
+    bay = rggb_frame(302, 514, 12)
+    bay[::37, ::41] = np.minimum(bay[::37, ::41] + 0.5, 1.0)
+    got = find_erroneous_pixels_threshold(raw(bay))
+    ref = orc.find_hot_threshold(bay)
+    assert all(np.array_equal(g, r) for g, r in zip(got, ref)) and sum(int(g.sum()) for g in got) > 10
+    yy, xx = np.mgrid[0:302, 0:514]
+    flat = (1.0 - 0.6 * ((yy - 151) ** 2 + (xx - 257) ** 2) / (151 ** 2 + 257 ** 2)).astype(np.float32)
+    flat[5, 5] = 0.0
+    img = raw(bay.copy())
+    flat_frame_correction(img, raw(flat))
+    assert np.array_equal(img.sensor_scaled, orc.flat_field(bay, flat), equal_nan=True)

@@ -136,3 +136,14 @@ def test_g9_fuse_from_debayer(orc):
     M = orc.final_matrix(d["xyz2cam"], d["white_xyz"])
     fused, cnt, _ = orc.fuse_rgb(list(d["rgb"]), meta["evs"], 1.0 / d["mult"], M)
     assert np.array_equal(fused, d["fused"]) and np.array_equal(cnt, d["count"])
+
+
+def test_g11_cleanup(orc):
+    d, _ = load_golden("g11_cleanup")
+    for i, m in enumerate(orc.find_hot_threshold(d["hot"])):
+        assert np.array_equal(m, d[f"mask{i}"])
+    for i, m in enumerate(orc.find_hot_threshold(d["hot"], 0.01, 3)):
+        assert np.array_equal(m, d[f"maskb{i}"])
+    assert np.array_equal(orc.flat_field(d["bayer"], d["flat"]), d["corrected"], equal_nan=True)
+    assert np.array_equal(orc.flat_field(d["bayer"], d["flat"], True), d["corrected_clamped"], equal_nan=True)
+    assert np.array_equal(orc.flat_field(d["bayer"], np.zeros_like(d["flat"])), d["corrected_zero_flat"], equal_nan=True)
