@@ -522,3 +522,26 @@ def test_hot_pixel_threshold_and_flat_field(orc):
     img = raw(bay.copy())
     flat_frame_correction(img, raw(flat))
     assert np.array_equal(img.sensor_scaled, orc.flat_field(bay, flat), equal_nan=True)
+
+
+def test_demosaic_extreme_values_vs_oracle(orc, wbobj):
+    """Out-of-range (negative, > 1), all-zero, all-one and denormal mosaics: same bits as the oracle (no NaNs involved)."""
+    from pysp_amd.const import QualityDemosaic
+    wb, M = _wbM(orc)
+    rng = np.random.default_rng(99)
+    H, W = 90, 118
+    cases = {
+        "signed": (rng.random((H, W), dtype=np.float32) * 1.7 - 0.2).astype(np.float32),
+        "zeros": np.zeros((H, W), np.float32),
+        "ones": np.ones((H, W), np.float32),
+        "denormal": (rng.random((H, W), dtype=np.float32) * np.float32(1e-39)).astype(np.float32),
+        "steps": np.kron(rng.integers(0, 2, (H // 6, W // 2)).astype(np.float32), np.ones((6, 2), np.float32))[:H, :W].copy(),
+    }
+    for name, bay in cases.items():
+        bay = np.ascontiguousarray(bay[:H - H % 2, :W - W % 2])
+        assert np.array_equal(_raw(bay, wbobj).demosaic(QualityDemosaic.Draft).image, orc.demosaic_draft(bay, wb)), name
+        assert np.array_equal(_raw(bay, wbobj).demosaic(QualityDemosaic.Fast).image, orc.demosaic_eag(bay, wb)), name
+        for hdr in (False, True):
+            got = _raw(bay, wbobj, hdr=hdr).demosaic(QualityDemosaic.Best, 1).image
+            ref = orc.demosaic_ahd(bay, wb, M, hdr, 1)
+            assert np.array_equal(got, ref, equal_nan=True), (name, hdr)
