@@ -50,6 +50,9 @@ def main() -> None:
     ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams (contexts) the frames of a rank are cycled over: consecutive frames are independent, so the "
+                         "next frame's first kernel fills the drain of the previous frame's last one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
@@ -96,19 +99,22 @@ def main() -> None:
     wb = _lib.wb3(wb_np)
     M = _lib.mat9(M_np)
 
-    ctx = _lib.Context(dev_index)             # own HIP stream; kernels are timed with events on THAT stream
+    n_streams = max(1, args.streams)
+    ctxs = [_lib.Context(dev_index) for _ in range(n_streams)]   # own HIP streams; kernels are timed with events on THOSE streams
+    ctx = ctxs[0]
     L = _lib.lib()
     alg_bytes_per_px = ALG_BYTES_PER_PX
 
     if quality >= 0:
         # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
         frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
-        out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(n_streams)]
 
         def step(i: int) -> None:
             f = frames[i % len(frames)]
-            _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, tail,
-                                           ctypes.c_void_p(out.data_ptr())))
+            s = i % n_streams                       # frame i runs on stream s, writing that stream's output buffer
+            _lib.check(L.pysp_pipeline_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, tail,
+                                           ctypes.c_void_p(outs[s].data_ptr())))
     elif quality == -1:
         K = 7
         base = rggb_frame(H, W, 1000 + rank, scale=8.0, clip_hi=False)
@@ -140,7 +146,8 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def fence() -> None:
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -150,12 +157,14 @@ def main() -> None:
     fence()
 
     # ---- timed region: exactly K steps, nothing but the kernels on the stream (no event records inside)
-    ctx.set_kernel_timing(0)
+    for c in ctxs:
+        c.set_kernel_timing(0)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    ctx.sync()
+    for c in ctxs:
+        c.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -167,10 +176,12 @@ def main() -> None:
 
     # ---- per-kernel durations: the same steps again, each kernel bracketed by HIP events on the launch
     # stream (recording them inside the timed region would add ~50 us of event traffic to every 1.1 ms step)
+    # (one stream only here, so that a kernel's duration is not stretched by a neighbour sharing the CUs)
+    fence()
     ctx.set_kernel_timing(2)
     samples: dict = {}
     for i in range(min(16, max(4, args.steps))):
-        step(i)
+        step(i * n_streams)
         for name, ms in ctx.kernel_times():
             samples.setdefault(name, []).append(ms)
     ctx.set_kernel_timing(1)
@@ -223,7 +234,7 @@ def main() -> None:
         "value": round(value, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": desc, "H": H, "W": W, "frames_per_rank_resident": len(frames), "sharding": "frame-parallel, no data-path collective; WB/CCM broadcast once over RCCL"},
+        "config": {"workload": desc, "H": H, "W": W, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams, "sharding": "frame-parallel, no data-path collective; WB/CCM broadcast once over RCCL"},
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(line), flush=True)
