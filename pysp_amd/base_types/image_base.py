@@ -1,7 +1,8 @@
-"""Image containers (reference base_types/image_base.py:13-124)."""
+"""Containers for raw mosaics and demosaiced images, attribute-compatible with the reference's
+base_types/image_base.py (:13-124); the pixel work they trigger runs on the GPU."""
 from __future__ import annotations
 
-from enum import IntEnum, auto
+import enum
 from typing import Optional
 
 import numpy as np
@@ -11,86 +12,93 @@ from ..colorize.transform import cam_to_lin_srgb
 from ..const import QualityDemosaic
 from ..wb_cct.helpers_cam_mat import MatXyzToCamera
 
-
-class BayerPattern(IntEnum):
-    Rggb = auto()
-    Bggr = auto()
-    Grbg = auto()
-    Gbrg = auto()
+BayerPattern = enum.IntEnum("BayerPattern", ("Rggb", "Bggr", "Grbg", "Gbrg"), module=__name__)
 
 
 class RawDemosaicData:
-    """RGB pixels after demosaicing: (H, W, 3) float32, camera space, white balance applied."""
+    """(H, W, 3) float32 camera-space RGB produced by a demosaic, plus what is needed to colour it."""
 
     def __init__(self, image: np.ndarray, wb_coeff: np.ndarray, wb_norm: bool = False):
-        self.image: np.ndarray = image
-        self._wb_coeff: np.ndarray = wb_coeff
-        self._wb_applied: bool = True
-        self._wb_normalized: bool = wb_norm
+        self.image = image                 # white-balanced camera RGB
         self.mat_xyz: Optional[MatXyzToCamera] = None
         self.current_ev: float = np.inf
+        self._wb_coeff = wb_coeff          # reciprocal neutral multipliers, at least 3 entries
+        self._wb_applied = True            # every demosaic path multiplies them in (ahd.py:77-80, eag.py:193-194)
+        self._wb_normalized = wb_norm
 
     def is_valid(self) -> bool:
-        return self.image is not None and self._wb_coeff is not None and self.mat_xyz is not None and self.current_ev != np.inf
+        """Image, coefficients, matrix and exposure value are all present."""
+        have = (self.image is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
+        return all(have)
 
-    def _scale(self, coeff, undo: bool) -> np.ndarray:
-        a = _lib.f32c(self.image)
-        out = np.empty_like(a)
-        _lib.check(_lib.lib().pysp_wb_scale_f32(_lib.default_context().handle, _lib.ptr(a), a.size // 3, _lib.wb3(coeff), int(undo), _lib.ptr(out)))
-        return out
+    def _gpu_scale(self, undo: bool) -> np.ndarray:
+        src = _lib.f32c(self.image)
+        dst = np.empty_like(src)
+        _lib.check(_lib.lib().pysp_wb_scale_f32(_lib.default_context().handle, _lib.ptr(src), src.size // 3,
+                                                _lib.wb3(self._wb_coeff), int(undo), _lib.ptr(dst)))
+        return dst
 
     def wb_apply(self):
-        """image * coeff[:3] as float32, if not applied yet (image_base.py:45-50)."""
-        if not self._wb_applied:
-            self.image = self._scale(self._wb_coeff, undo=False)
-            self._wb_applied = True
+        """Multiply the coefficients in (float32) unless they already are (image_base.py:45-50)."""
+        if self._wb_applied:
+            return
+        self.image = self._gpu_scale(undo=False)
+        self._wb_applied = True
 
     def wb_undo(self):
-        """Back to pure camera space through a float64 divide (image_base.py:52-60)."""
-        if self._wb_applied:
-            if self._wb_normalized:
-                self.image = self.image * max(self._wb_coeff)
-            self.image = self._scale(self._wb_coeff, undo=True)
-            self._wb_applied = False
-            self._wb_normalized = False
+        """Divide the coefficients out through float64 (image_base.py:52-60); drops any normalisation first."""
+        if not self._wb_applied:
+            return
+        if self._wb_normalized:
+            self.image = self.image * max(self._wb_coeff)
+        self.image = self._gpu_scale(undo=True)
+        self._wb_applied = self._wb_normalized = False
 
     def to_lin_srgb(self) -> np.ndarray:
+        """Linear sRGB through the camera matrix, highlights clipped (image_base.py:62-64)."""
         self.wb_apply()
         return cam_to_lin_srgb(self.image, self.mat_xyz)
 
 
 class RawCameraData_BaseType:
+    """What every raw container carries: normalised sensor data, white balance, exposure, saturation limit."""
+
+    sensor_scaled: Optional[np.ndarray]
+
     def __init__(self):
-        self.sensor_scaled: np.ndarray = None
+        self.sensor_scaled = None
         self.cam_wb = None
-        self.current_ev: float = np.inf
-        self.lim_sat: float = 1.0
-        self.__is_hdr: bool = False
+        self.current_ev = np.inf
+        self.lim_sat = 1.0
+        self._hdr_flag = False
 
     def set_hdr(self, is_hdr: bool):
-        self.__is_hdr = is_hdr
+        self._hdr_flag = is_hdr
 
     def get_hdr(self) -> bool:
-        return self.__is_hdr
+        return self._hdr_flag
 
-    def demosaic(self, quality: QualityDemosaic, postprocess_steps: int = 1) -> RawDemosaicData:
+    def demosaic(self, quality: QualityDemosaic, postprocess_steps: int = 1) -> Optional[RawDemosaicData]:
+        """Overridden by the concrete containers in pysp_amd.image."""
         return None
 
 
 class RawBayerData_BaseType(RawCameraData_BaseType):
+    """A mosaic in its native CFA orientation."""
+
     def __init__(self):
         super().__init__()
-        self.sensor_pattern: BayerPattern = None
+        self.sensor_pattern: Optional[BayerPattern] = None
 
-    def to_rggb(self) -> "RawRggbBayerData_BaseType":
+    def to_rggb(self) -> Optional["RawRggbBayerData_BaseType"]:
         return None
 
 
 class RawRggbBayerData_BaseType(RawCameraData_BaseType):
+    """A mosaic already flipped/rotated so that it reads RGGB; remembers where it came from."""
+
     def __init__(self, sensor_scaled: np.ndarray, cam_wb, shot_ev: float, lim_sat: float, source_pattern=BayerPattern.Rggb):
         super().__init__()
-        self.sensor_scaled = sensor_scaled
-        self.cam_wb = cam_wb
-        self.current_ev = shot_ev
-        self.lim_sat = lim_sat
-        self.source_pattern: BayerPattern = source_pattern
+        self.sensor_scaled, self.cam_wb = sensor_scaled, cam_wb
+        self.current_ev, self.lim_sat = shot_ev, lim_sat
+        self.source_pattern = source_pattern

@@ -1,40 +1,49 @@
-"""Linear RGB working spaces (reference colorize/rgb_space.py:7-56).  Host-side float64."""
-from typing import Optional, Tuple, Union
+"""Linear RGB working spaces: primaries + white -> RGB->XYZ matrix, optionally Bradford-adapted.
+Host-side float64 3x3 algebra (what the reference does in colorize/rgb_space.py:19-52)."""
+from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
 
 from ..wb_cct.helpers_cam_mat import bradford_adapt_matrix, xy_to_XYZ
 from ..wb_cct.standard_ill import StandardIlluminant, get_chromacity_from_illuminant
 
+XY = Tuple[float, float]
+White = Union[Sequence[float], StandardIlluminant]
+
+
+def _white_xyz(w: White) -> np.ndarray:
+    if isinstance(w, StandardIlluminant):
+        return xy_to_XYZ(get_chromacity_from_illuminant(w))
+    xyz = np.array(w)
+    if xyz.ndim != 1 or xyz.shape[0] != 3:
+        raise ValueError("white point must be an XYZ triple or a StandardIlluminant")
+    return xyz
+
 
 class ArbitraryRgbColorspace:
-    def __init__(self, primary_xy_r: Tuple[float, float], primary_xy_g: Tuple[float, float], primary_xy_b: Tuple[float, float],
-                 whitepoint: StandardIlluminant):
-        self._prim = (primary_xy_r, primary_xy_g, primary_xy_b)
-        self._white = xy_to_XYZ(get_chromacity_from_illuminant(whitepoint))
+    """An RGB space given by the xy chromaticities of its primaries and a standard-illuminant white."""
 
-    def mat_to_rgb(self, source_whitepoint=None) -> np.ndarray:
-        return np.linalg.inv(self.mat_to_xyz(source_whitepoint))
+    def __init__(self, primary_xy_r: XY, primary_xy_g: XY, primary_xy_b: XY, whitepoint: StandardIlluminant):
+        self._xy = np.array([primary_xy_r, primary_xy_g, primary_xy_b], dtype=np.float64)   # rows: R, G, B
+        self._white = _white_xyz(whitepoint)
 
-    def mat_to_xyz(self, destination_whitepoint: Optional[Union[Tuple[float, float, float], StandardIlluminant]] = None) -> np.ndarray:
-        """RGB -> XYZ with the primaries scaled so that RGB white hits the space's white, optionally
-        Bradford-adapted to another white (pre-multiplied, rgb_space.py:47-50)."""
-        m = np.array([[p[0] / p[1] for p in self._prim],
-                      [1, 1, 1],
-                      [(1 - p[0] - p[1]) / p[1] for p in self._prim]], dtype=np.float64)
-        s = np.linalg.inv(m) @ self._white
-        m[:, 0] *= s[0]
-        m[:, 1] *= s[1]
-        m[:, 2] *= s[2]
+    def _unscaled(self) -> np.ndarray:
+        x, y = self._xy[:, 0], self._xy[:, 1]
+        return np.array([x / y, [1, 1, 1], (1 - x - y) / y], dtype=np.float64)   # columns: XYZ of each primary at Y = 1
+
+    def mat_to_xyz(self, destination_whitepoint: Optional[White] = None) -> np.ndarray:
+        """RGB -> XYZ.  Primaries are scaled so that RGB = (1,1,1) lands on the space's white; with a destination
+        white the Bradford adaptation from the space's white is applied on the left (rgb_space.py:47-50)."""
+        m = self._unscaled()
+        gains = np.linalg.inv(m) @ self._white
+        for col in range(3):
+            m[:, col] *= gains[col]
         if destination_whitepoint is None:
             return m
-        if isinstance(destination_whitepoint, StandardIlluminant):
-            dest = xy_to_XYZ(get_chromacity_from_illuminant(destination_whitepoint))
-        else:
-            dest = np.array(destination_whitepoint)
-        if dest.ndim != 1 or dest.shape[0] != 3:
-            raise ValueError("white point must be an XYZ triple")
-        return bradford_adapt_matrix(self._white, dest) @ m
+        return bradford_adapt_matrix(self._white, _white_xyz(destination_whitepoint)) @ m
+
+    def mat_to_rgb(self, source_whitepoint: Optional[White] = None) -> np.ndarray:
+        return np.linalg.inv(self.mat_to_xyz(source_whitepoint))
 
 
 class LinRgbColorspace:
