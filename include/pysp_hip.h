@@ -70,6 +70,14 @@ int pysp_rgbg_to_bayer_f32(pysp_ctx *ctx, const float *r, const float *g1, const
 /* normalization.py:4-24 bayer_normalize; black/sat indexed r,g1,b,g2 */
 int pysp_bayer_normalize_u16(pysp_ctx *ctx, const uint16_t *bayer, int H, int W, const float black[4], const float sat[4], float *out);
 
+/* ---- Stand-alone EAG helpers (public functions of debayer/edge_assisted_gaussian.py) -----------
+ * :51-124 resample_g_to_full_resolution(g1, g2, use_bilinear_weighting): (h,w),(h,w) -> (2h,2w). */
+int pysp_resample_g_f32(pysp_ctx *ctx, const float *g1, const float *g2, int h, int w, int use_bilinear_weighting, float *out);
+/* :126-143 resample_channel(subpixel, g_at_subpixel, g_hf_pass, bayer_position) when g_full == NULL;
+ * :160-186 resample_r / resample_b(channel, g_upscaled) when g_full != NULL (g_sub, g_hf ignored: the high-pass
+ * and the green at the photosite are derived from g_full).  bayer_position: 0 TOP_LEFT, 3 BOTTOM_RIGHT. */
+int pysp_resample_channel_f32(pysp_ctx *ctx, const float *sub, const float *g_sub, const float *g_hf, const float *g_full, int h, int w, int bayer_position, float *out);
+
 /* ---- pre-demosaic cleanup (the step before the path) -----------------------------------------
  * raw_bad_pixel_corr.py:30-65 find_erroneous_pixels_threshold: four (H/2,W/2) uint8 masks (1 = hot) for the
  * r,g1,b,g2 planes. */

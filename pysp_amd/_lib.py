@@ -42,6 +42,8 @@ _SIGNATURES = {
     "pysp_bayer_to_rgbg_u16": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pysp_rgbg_to_bayer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),
     "pysp_bayer_normalize_u16": (_int, [_vp, _vp, _int, _int, _f32p, _f32p, _vp]),
+    "pysp_resample_g_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    "pysp_resample_channel_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
     "pysp_find_hot_pixels_f32": (_int, [_vp, _vp, _int, _int, _flt, _int, _vp, _vp, _vp, _vp]),
     "pysp_flat_field_f32": (_int, [_vp, _vp, _vp, _int, _int, _f32p, _int, _vp]),
     "pysp_build_map_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),

@@ -236,6 +236,47 @@ int pysp_build_map_f32(pysp_ctx* ctx, const float* lab, int Hp, int Wp, int k_pa
     return pysp_ctx_sync(ctx);
 }
 
+// ---- stand-alone EAG helpers ---------------------------------------------------------------------------
+int pysp_resample_g_f32(pysp_ctx* ctx, const float* g1, const float* g2, int h, int w, int use_bilinear_weighting, float* out) {
+    CTX_ENTER(ctx);
+    if (!g1 || !g2 || !out || h < 1 || w < 1) return fail(PYSP_EBADARG, "resample_g: bad arguments");
+    size_t n = (size_t)h * w;
+    float *d1, *d2, *d_out;
+    RESERVE(ctx, S_P0, n * 4, d1); RESERVE(ctx, S_P0 + 1, n * 4, d2); RESERVE(ctx, S_OUT, n * 16, d_out);
+    TRY(h2d(ctx, d1, g1, n * 4)); TRY(h2d(ctx, d2, g2, n * 4));
+    ctx->tic();
+    LAUNCH_TRY(launch_resample_g(ctx->stream, d1, d2, h, w, use_bilinear_weighting != 0, d_out));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, n * 16));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_resample_channel_f32(pysp_ctx* ctx, const float* sub, const float* g_sub, const float* g_hf, const float* g_full, int h, int w,
+                              int bayer_position, float* out) {
+    CTX_ENTER(ctx);
+    if (!sub || !out || h < 1 || w < 1 || (!g_hf && !g_full) || (!g_sub && !g_full)) return fail(PYSP_EBADARG, "resample_channel: bad arguments");
+    if (bayer_position != 0 && bayer_position != 3) return fail(PYSP_ENOTIMPL, "resample_channel: only TOP_LEFT (0) and BOTTOM_RIGHT (3) bases are used by the reference");
+    size_t n = (size_t)h * w;
+    float *d_sub, *d_gsub, *d_hf, *d_out, *d_full = nullptr;
+    RESERVE(ctx, S_P0, n * 4, d_sub); RESERVE(ctx, S_P0 + 1, n * 4, d_gsub); RESERVE(ctx, S_TMP0, n * 16, d_hf); RESERVE(ctx, S_OUT, n * 16, d_out);
+    TRY(h2d(ctx, d_sub, sub, n * 4));
+    ctx->tic();
+    if (g_full) {   // resample_r / resample_b (eag.py:160-186): hf and g at the photosite both come from the full-resolution green
+        float *t1, *t2, *t3;
+        RESERVE(ctx, S_IN, n * 16, d_full); RESERVE(ctx, S_P0 + 2, n * 4, t1); RESERVE(ctx, S_P0 + 3, n * 4, t2); RESERVE(ctx, S_AUX, n * 4, t3);
+        TRY(h2d(ctx, d_full, g_full, n * 16));
+        LAUNCH_TRY(launch_highpass(ctx->stream, d_full, 2 * h, 2 * w, d_hf));
+        // bayer_to_rgbg(g_upscaled): r-site plane for TOP_LEFT, b-site plane for BOTTOM_RIGHT
+        if (bayer_position == 0) LAUNCH_TRY(launch_demux_f32(ctx->stream, d_full, 2 * h, 2 * w, d_gsub, t1, t2, t3));
+        else LAUNCH_TRY(launch_demux_f32(ctx->stream, d_full, 2 * h, 2 * w, t1, t2, d_gsub, t3));
+    } else {
+        TRY(h2d(ctx, d_gsub, g_sub, n * 4)); TRY(h2d(ctx, d_hf, g_hf, n * 16));
+    }
+    LAUNCH_TRY(launch_resample_channel(ctx->stream, d_sub, d_gsub, d_hf, h, w, bayer_position, d_out));
+    ctx->toc();
+    TRY(d2h(ctx, out, d_out, n * 16));
+    return pysp_ctx_sync(ctx);
+}
+
 // ---- pre-demosaic cleanup -------------------------------------------------------------------------------
 int pysp_find_hot_pixels_f32(pysp_ctx* ctx, const float* bayer, int H, int W, float min_delta, int min_neighbour_count, uint8_t* mask_r,
                              uint8_t* mask_g1, uint8_t* mask_b, uint8_t* mask_g2) {

@@ -212,6 +212,85 @@ int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// ================================================================================================
+// Stand-alone forms of the public helpers of edge_assisted_gaussian.py (used by callers outside the fused
+// demosaic, e.g. corr_ca/ca_removal.py:90,105,122).  Plain one-thread-per-quad kernels on global memory:
+// neighbours are L2 hits; these are not on the fused hot path.
+namespace {
+template <int STRIDE_UNUSED = 0>
+DEVI Win3 load_win_global(const float* plane, int h, int w, int i, int j) {   // 3x3, REFLECT_101 on the quarter plane
+    Win3 wn;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) wn.v[r][c] = plane[(size_t)b_101(i - 1 + r, h) * w + b_101(j - 1 + c, w)];
+    return wn;
+}
+}  // namespace
+
+// eag.py:51-124 resample_g_to_full_resolution: g1, g2 (h,w) -> (2h,2w)
+__global__ void __launch_bounds__(256) k_resample_g(const float* __restrict__ g1, const float* __restrict__ g2, int h, int w, int weighted,
+                                                    float* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= w) return;
+    auto G1 = [&](int a, int c) { return g1[(size_t)b_sym(a, h) * w + b_sym(c, w)]; };   // copyMakeBorder(..., BORDER_REFLECT)
+    auto G2 = [&](int a, int c) { return g2[(size_t)b_sym(a, h) * w + b_sym(c, w)]; };
+    float rt = G2(i - 1, j), rb = G2(i, j), rl = G1(i, j - 1), rr = G1(i, j);                // red site   (:105-108)
+    float bt = G1(i, j), bb = G1(i + 1, j), bl = G2(i, j), br = G2(i, j + 1);                // blue site  (:99-102)
+    float gr, gb;
+    if (weighted) { gr = delta_mix(rt, rb, rl, rr); gb = delta_mix(bt, bb, bl, br); }
+    else { gr = (((rt + rb) + rl) + rr) / 4.0f; gb = (((bt + bb) + bl) + br) / 4.0f; }       // :113-114
+    size_t W = 2 * (size_t)w;
+    out[(size_t)(2 * i) * W + 2 * j] = gr; out[(size_t)(2 * i) * W + 2 * j + 1] = g1[(size_t)i * w + j];
+    out[(size_t)(2 * i + 1) * W + 2 * j] = g2[(size_t)i * w + j]; out[(size_t)(2 * i + 1) * W + 2 * j + 1] = gb;
+}
+// g - cv2.GaussianBlur(g,(3,3),1.0) (eag.py:156,170,184) on a full-resolution plane, REFLECT_101
+__global__ void __launch_bounds__(256) k_highpass(const float* __restrict__ g, int H, int W, float* __restrict__ out) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    int xs[3] = {b_101(x - 1, W), x, b_101(x + 1, W)}, ys[3] = {b_101(y - 1, H), y, b_101(y + 1, H)};
+    float rb[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float* row = g + (size_t)ys[r] * W;
+        rb[r] = row[xs[1]] * GK0 + (row[xs[0]] + row[xs[2]]) * GK1;
+    }
+    out[(size_t)y * W + x] = g[(size_t)y * W + x] - (rb[1] * GK0 + (rb[0] + rb[2]) * GK1);
+}
+// eag.py:126-143 resample_channel: sub, g_sub (h,w); g_hf (2h,2w); pos 0 = TOP_LEFT, 3 = BOTTOM_RIGHT (the two the
+// reference uses); one thread per quad.
+__global__ void __launch_bounds__(256) k_resample_channel(const float* __restrict__ sub, const float* __restrict__ g_sub,
+                                                          const float* __restrict__ g_hf, int h, int w, int pos, float* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= w) return;
+    Win3 wg = load_win_global<>(g_sub, h, w, i, j), ws = load_win_global<>(sub, h, w, i, j), wd;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) wd.v[r][c] = ws.v[r][c] - wg.v[r][c];        // channel_diff (:142), elementwise before the filter
+    float fg[4], fd[4];
+    if (pos == 0) { filt_base_tl(wg, fg); filt_base_tl(wd, fd); } else { filt_base_br(wg, fg); filt_base_br(wd, fd); }
+    size_t W = 2 * (size_t)w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        size_t o = (size_t)(2 * i + (k >> 1)) * W + 2 * j + (k & 1);
+        out[o] = fd[k] + (fg[k] + g_hf[o]);
+    }
+}
+int launch_resample_g(hipStream_t st, const float* g1, const float* g2, int h, int w, int weighted, float* out) {
+    hipLaunchKernelGGL(k_resample_g, dim3((w + 255) / 256, h), dim3(256), 0, st, g1, g2, h, w, weighted, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_highpass(hipStream_t st, const float* g, int H, int W, float* out) {
+    hipLaunchKernelGGL(k_highpass, dim3((W + 255) / 256, H), dim3(256), 0, st, g, H, W, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_resample_channel(hipStream_t st, const float* sub, const float* g_sub, const float* g_hf, int h, int w, int pos, float* out) {
+    if (pos != 0 && pos != 3) return -1;
+    hipLaunchKernelGGL(k_resample_channel, dim3((w + 255) / 256, h), dim3(256), 0, st, sub, g_sub, g_hf, h, w, pos, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 MosaicSrc mosaic_f32(const float* d_bayer) {
     MosaicSrc m;
     m.f32 = d_bayer; m.u16 = nullptr;

@@ -42,6 +42,10 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
 int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
 int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
 
+int launch_resample_g(hipStream_t st, const float* g1, const float* g2, int h, int w, int weighted, float* out);
+int launch_highpass(hipStream_t st, const float* g, int H, int W, float* out);
+int launch_resample_channel(hipStream_t st, const float* sub, const float* g_sub, const float* g_hf, int h, int w, int pos, float* out);
+
 // k_misc.hip
 int launch_fuse_raw(hipStream_t st, const float* const* d_frames_host_array, int K, int H, int W, const float* ev_off,
                     const float* bias, int kmax, float* d_out, int32_t* d_count);

@@ -93,3 +93,12 @@ def test_synth_frame_is_deterministic():
     a, b = rggb_frame(64, 96, 1003), rggb_frame(64, 96, 1003)
     assert a.dtype == np.float32 and np.array_equal(a, b) and 0 <= a.min() and a.max() <= 1
     assert not np.array_equal(a, rggb_frame(64, 96, 1004))
+
+
+def test_get_rgbg_kernel_host_matches_reference_fixture():
+    from conftest import load_golden
+    from pysp_amd.debayer.gaussian import BayerPatternPosition, CV2_DEFAULT_UNNORM_GAUSSIAN_KERNEL, get_rgbg_kernel
+    k, _ = load_golden("g2_rgbg_kernel")
+    for pos in BayerPatternPosition:
+        for i, kern in enumerate(get_rgbg_kernel(CV2_DEFAULT_UNNORM_GAUSSIAN_KERNEL, pos)):
+            assert np.array_equal(kern, k[f"pos{pos.value}_k{i}"])

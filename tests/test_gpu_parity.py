@@ -545,3 +545,34 @@ def test_demosaic_extreme_values_vs_oracle(orc, wbobj):
             got = _raw(bay, wbobj, hdr=hdr).demosaic(QualityDemosaic.Best, 1).image
             ref = orc.demosaic_ahd(bay, wb, M, hdr, 1)
             assert np.array_equal(got, ref, equal_nan=True), (name, hdr)
+
+
+def test_standalone_eag_helpers(orc):
+    """Public helpers of edge_assisted_gaussian.py / gaussian.py outside the fused kernel."""
+    from pysp_amd.debayer.edge_assisted_gaussian import resample_b, resample_channel, resample_g_to_full_resolution, resample_r, resample_rb
+    from pysp_amd.debayer.gaussian import BayerPatternPosition, CV2_DEFAULT_UNNORM_GAUSSIAN_KERNEL, get_rgbg_kernel
+    d, _ = load_golden("g8_resample")
+    assert np.array_equal(resample_channel(d["sub"], d["g_sub"], d["g_hf"], BayerPatternPosition.TOP_LEFT), d["out_tl"])
+    assert np.array_equal(resample_channel(d["sub"], d["g_sub"], d["g_hf"], BayerPatternPosition.BOTTOM_RIGHT), d["out_br"])
+    assert np.array_equal(resample_g_to_full_resolution(d["sub"], d["g_sub"]), d["g_full"])
+    k, _ = load_golden("g2_rgbg_kernel")
+    for pos in BayerPatternPosition:
+        for i, kern in enumerate(get_rgbg_kernel(CV2_DEFAULT_UNNORM_GAUSSIAN_KERNEL, pos)):
+            assert np.array_equal(kern, k[f"pos{pos.value}_k{i}"])
+    # resample_r / resample_b / resample_rb against the oracle's pieces, odd plane sizes, tiny planes
+    rng = np.random.default_rng(17)
+    for (h, w) in ((1, 1), (2, 3), (37, 53)):
+        r = rng.random((h, w), dtype=np.float32); b = rng.random((h, w), dtype=np.float32)
+        g1 = rng.random((h, w), dtype=np.float32); g2 = rng.random((h, w), dtype=np.float32)
+        g_up = resample_g_to_full_resolution(g1, g2)
+        assert np.array_equal(g_up, orc.resample_g_full(g1, g2))
+        hf = g_up - orc.gaussian_blur3(g_up)
+        planes = orc.bayer_to_rgbg(g_up)
+        assert np.array_equal(resample_r(r, g_up), orc.resample_channel(r, planes[0], hf, 0))
+        assert np.array_equal(resample_b(b, g_up), orc.resample_channel(b, planes[2], hf, 3))
+        rr, bb = resample_rb(r, b, g_up)
+        assert np.array_equal(rr, resample_r(r, g_up)) and np.array_equal(bb, resample_b(b, g_up))
+    plain = resample_g_to_full_resolution(d["sub"], d["g_sub"], use_bilinear_weighting=False)
+    assert np.array_equal(plain[0::2, 1::2], d["sub"]) and np.array_equal(plain[1::2, 0::2], d["g_sub"])
+    with pytest.raises(NotImplementedError):
+        resample_channel(d["sub"], d["g_sub"], d["g_hf"], BayerPatternPosition.TOP_RIGHT)
