@@ -102,3 +102,34 @@ def test_get_rgbg_kernel_host_matches_reference_fixture():
     for pos in BayerPatternPosition:
         for i, kern in enumerate(get_rgbg_kernel(CV2_DEFAULT_UNNORM_GAUSSIAN_KERNEL, pos)):
             assert np.array_equal(kern, k[f"pos{pos.value}_k{i}"])
+
+
+def test_reference_import_paths_exist():
+    """A pySP user's import lines for this path resolve (names only; calling them needs the GPU)."""
+    import importlib
+    for mod, names in {
+        "pysp_amd.const": ["QualityDemosaic", "PatternDemosaic"],
+        "pysp_amd.image": ["RawRggbBayerData", "RawBayerData", "RawBayerDataFromRaw", "RawRgbgDataFromRaw", "reversible_transform_rggb"],
+        "pysp_amd.base_types.image_base": ["BayerPattern", "RawDemosaicData", "RawRggbBayerData_BaseType", "RawBayerData_BaseType"],
+        "pysp_amd.bayer_chan_mixer": ["bayer_to_rgbg", "rgbg_to_bayer"],
+        "pysp_amd.normalization": ["bayer_normalize"],
+        "pysp_amd.debayer": ["debayer_ahd", "debayer_eag", "debayer_fast"],
+        "pysp_amd.debayer.ahd": ["debayer"],
+        "pysp_amd.debayer.fast_resize": ["debayer"],
+        "pysp_amd.debayer.edge_assisted_gaussian": ["debayer", "resample_channel", "resample_g_to_full_resolution", "resample_rb", "resample_r", "resample_b"],
+        "pysp_amd.debayer.gaussian": ["get_rgbg_kernel", "BayerPatternPosition", "CV2_DEFAULT_UNNORM_GAUSSIAN_KERNEL", "CV2_DEFAULT_KERNEL_SIGMA"],
+        "pysp_amd.debayer.ahd_homogeneity_cython": ["build_map"],
+        "pysp_amd.colorize": ["lin_srgb_to_srgb"],
+        "pysp_amd.colorize.transform": ["clip_rgb", "cam_to_rgb_norm", "cam_to_lin_srgb", "cam_to_clean_xyz", "lin_srgb_to_srgb", "srgb_to_lin_srgb"],
+        "pysp_amd.colorize.rgb_space": ["ArbitraryRgbColorspace", "LinRgbColorspace"],
+        "pysp_amd.wb_cct.helpers_cam_mat": ["MatXyzToCamera", "bradford_adapt_matrix"],
+        "pysp_amd.wb_cct.cam_wb": ["CameraWhiteBalanceController"],
+        "pysp_amd.raw_hdr": ["fuse_exposures_to_raw", "fuse_exposures_from_debayer"],
+        "pysp_amd.raw_bad_pixel_corr": ["find_erroneous_pixels_threshold", "find_shared_pixels"],
+        "pysp_amd.raw_correction": ["flat_frame_correction"],
+        "pysp_amd.dng_warp_corr": ["apply_opcode_3_warp", "stack_warp_prior"],
+        "pysp_amd.dng_warp_corr.dng_warp_rectilinear_coords": ["compute_remapping_table", "compute_offset_remapping_table"],
+    }.items():
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
