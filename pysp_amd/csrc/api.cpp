@@ -51,7 +51,7 @@ struct pysp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int timing_mode = 1;      // 0: no events, 1: one event pair per call (default), 2: plus one pair per kernel
-    static constexpr int NSLOT = 24;
+    static constexpr int NSLOT = 32;
     void* slot[NSLOT] = {};
     size_t cap[NSLOT] = {};
     float* lanczos = nullptr;

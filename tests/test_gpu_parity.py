@@ -576,3 +576,17 @@ def test_standalone_eag_helpers(orc):
     assert np.array_equal(plain[0::2, 1::2], d["sub"]) and np.array_equal(plain[1::2, 0::2], d["g_sub"])
     with pytest.raises(NotImplementedError):
         resample_channel(d["sub"], d["g_sub"], d["g_hf"], BayerPatternPosition.TOP_RIGHT)
+
+
+def test_fuse_raw_sixteen_exposures(orc, wbobj):
+    """Upper limit of the ABI: 16 exposures through the host entry point."""
+    from pysp_amd.raw_hdr import fuse_exposures_to_raw
+    rng = np.random.default_rng(4)
+    K, H, W = 16, 20, 36
+    frames = [rng.random((H, W), dtype=np.float32) for _ in range(K)]
+    evs = [8.0 + 0.25 * k for k in range(K)]
+    hdr, cnt = fuse_exposures_to_raw([_raw(f, wbobj, ev=e) for f, e in zip(frames, evs)])
+    ref, refc, _, _ = orc.fuse_raw(frames, evs, 1.0 / MULT)
+    assert np.array_equal(hdr.sensor_scaled, ref) and np.array_equal(cnt, refc)
+    with pytest.raises(ValueError):
+        fuse_exposures_to_raw([_raw(frames[0], wbobj, ev=9.0)] * 17)
