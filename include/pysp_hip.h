@@ -154,6 +154,10 @@ int pysp_warp_table_f32(pysp_ctx *ctx, float kr0, float kr1, float kr2, float kr
 /* dng_warp_corr/chan_distortion_corr.py:86-97: per plane table -> clip -> Lanczos-4 remap, in place
  * on an (H,W,3) image; coeffs = planes x {kr0..kr3,kt0,kt1} float64 as unpacked from the opcode. */
 int pysp_warp_rectilinear_f32(pysp_ctx *ctx, float *image, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale);
+/* Seeded variant (prior != None, :88-91): prior is the (H,W,3,2) float32 stack of stack_warp_prior (:11-41). */
+int pysp_warp_rectilinear_prior_f32(pysp_ctx *ctx, float *image, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale, const float *prior);
+/* The restated cv2.remap(plane, mapx, mapy, INTER_LANCZOS4) itself (:94-97), maps as given (no clipping). */
+int pysp_remap_lanczos4_f32(pysp_ctx *ctx, const float *src, int H, int W, const float *mapx, const float *mapy, float *dst);
 int pysp_warp_rectilinear_dev(pysp_ctx *ctx, const float *d_in, float *d_out, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale);
 
 #ifdef __cplusplus

@@ -520,6 +520,47 @@ int pysp_warp_table_f32(pysp_ctx* ctx, float kr0, float kr1, float kr2, float kr
     TRY(d2h(ctx, table, d_tab, n * 4));
     return pysp_ctx_sync(ctx);
 }
+int pysp_remap_lanczos4_f32(pysp_ctx* ctx, const float* src, int H, int W, const float* mapx, const float* mapy, float* dst) {
+    CTX_ENTER(ctx);
+    if (!src || !mapx || !mapy || !dst || H < 1 || W < 1) return fail(PYSP_EBADARG, "remap: bad arguments");
+    size_t n = (size_t)H * W;
+    float *d_src, *d_mx, *d_my, *d_dst;
+    RESERVE(ctx, S_IN, n * 4, d_src); RESERVE(ctx, S_P0, n * 4, d_mx); RESERVE(ctx, S_P0 + 1, n * 4, d_my); RESERVE(ctx, S_OUT, n * 4, d_dst);
+    TRY(h2d(ctx, d_src, src, n * 4)); TRY(h2d(ctx, d_mx, mapx, n * 4)); TRY(h2d(ctx, d_my, mapy, n * 4));
+    ctx->tic();
+    LAUNCH_TRY(launch_remap_table(ctx->stream, d_src, 1, d_mx, d_my, 1, ctx->lanczos, H, W, 0, d_dst, 1));
+    ctx->toc();
+    TRY(d2h(ctx, dst, d_dst, n * 4));
+    return pysp_ctx_sync(ctx);
+}
+// chan_distortion_corr.py:86-97 with a prior: per plane seeded table (pyx:82-96) -> clip -> remap, in place on (H,W,3).
+// prior: (H,W,3,2) float32 as built by stack_warp_prior (:11-41).
+int pysp_warp_rectilinear_prior_f32(pysp_ctx* ctx, float* image, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm,
+                                    float scale, const float* prior) {
+    CTX_ENTER(ctx);
+    if (!image || !coeffs || !prior || H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_rectilinear_prior: bad arguments");
+    if (planes != 3) return fail(PYSP_EBADARG, "warp_rectilinear_prior: plane count %d does not match a 3-channel image", planes);
+    size_t n = (size_t)H * W;
+    float *d_img, *d_out, *d_seed, *d_tab;
+    RESERVE(ctx, S_IN, n * 12, d_img); RESERVE(ctx, S_OUT, n * 12, d_out); RESERVE(ctx, S_TMP0, n * 8, d_seed); RESERVE(ctx, S_TMP1, n * 8, d_tab);
+    std::vector<float> seed(n * 2);
+    TRY(h2d(ctx, d_img, image, n * 12));
+    ctx->tic();
+    for (int c = 0; c < 3; c++) {
+        for (size_t i = 0; i < n; i++) { seed[2 * i] = prior[(i * 3 + c) * 2]; seed[2 * i + 1] = prior[(i * 3 + c) * 2 + 1]; }
+        TRY(h2d(ctx, d_seed, seed.data(), n * 8));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));      // `seed` is reused for the next plane
+        const double* k = coeffs + 6 * c;
+        LAUNCH_TRY(launch_warp_table(ctx->stream, (float)k[0], (float)k[1], (float)k[2], (float)k[3], (float)k[4], (float)k[5], W, H, (float)cx_norm,
+                                     (float)cy_norm, scale, d_seed, d_tab));
+        // the reference remaps plane c of the image in place, plane by plane: later planes see earlier results only in
+        // their own channel, so reading from the untouched input copy is equivalent
+        LAUNCH_TRY(launch_remap_table(ctx->stream, d_img + c, 3, d_tab, d_tab + 1, 2, ctx->lanczos, H, W, 1, d_out + c, 3));
+    }
+    ctx->toc();
+    TRY(d2h(ctx, image, d_out, n * 12));
+    return pysp_ctx_sync(ctx);
+}
 int pysp_warp_rectilinear_dev(pysp_ctx* ctx, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale) {
     CTX_ENTER(ctx);
     if (!d_in || !d_out || !coeffs || d_in == d_out) return fail(PYSP_EBADARG, "warp_rectilinear: null or aliased buffers");

@@ -337,6 +337,50 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
         o[0] = res[0]; o[1] = res[1]; o[2] = res[2];
     }
 }
+// Generic restated cv2.remap(plane, mapx, mapy, INTER_LANCZOS4), BORDER_CONSTANT 0 (chan_distortion_corr.py:94-97 with
+// an explicit table: the seeded / prior path).  src/dst element stride lets a plane of an interleaved image be used.
+__global__ void __launch_bounds__(256) k_remap_table(const float* __restrict__ src, int sstride, const float* __restrict__ mapx,
+                                                     const float* __restrict__ mapy, int mstride, const float* __restrict__ tab, int H, int W,
+                                                     float clip_x, float clip_y, int do_clip, float* __restrict__ dst, int dstride) {
+    __shared__ float stab[256];
+    stab[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    size_t o = (size_t)y * W + x;
+    float mx = mapx[o * mstride], my = mapy[o * mstride];
+    if (do_clip) {   // np.clip(map, 0, size-1), chan_distortion_corr.py:95-96
+        mx = mx < 0.0f ? 0.0f : (mx > clip_x ? clip_x : mx);
+        my = my < 0.0f ? 0.0f : (my > clip_y ? clip_y : my);
+    }
+    int sx = (int)rintf(mx * 32.0f), sy = (int)rintf(my * 32.0f);
+    int ix = (sx >> 5) - 3, iy = (sy >> 5) - 3;
+    const float* wx = stab + 8 * (sx & 31);
+    const float* wy = stab + 8 * (sy & 31);
+    float sum = 0.0f;
+    for (int r = 0; r < 8; r++) {
+        int yy = iy + r;
+        bool yin = (unsigned)yy < (unsigned)H;
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            int xx = ix + t;
+            float s = (yin && (unsigned)xx < (unsigned)W) ? src[((size_t)yy * W + xx) * sstride] : 0.0f;
+            float v = s * (wy[r] * wx[t]);
+            acc = t == 0 ? v : acc + v;
+        }
+        sum = sum + acc;
+    }
+    dst[o * dstride] = sum;
+}
+int launch_remap_table(hipStream_t st, const float* src, int sstride, const float* mapx, const float* mapy, int mstride, const float* d_tab,
+                       int H, int W, int do_clip, float* dst, int dstride) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_remap_table, grid, dim3(256), 0, st, src, sstride, mapx, mapy, mstride, d_tab, H, W, (float)(W - 1), (float)(H - 1), do_clip,
+                       dst, dstride);
+    return CHECK_LAUNCH();
+}
+
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
                       double cyn, float scale, const float* d_lanczos_tab) {
     if (planes != 3) return -1;

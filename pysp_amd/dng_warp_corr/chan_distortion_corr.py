@@ -37,14 +37,15 @@ def _warp_rectilinear(image: np.ndarray, data: bytes, scale: float, prior) -> bo
         return False
     coeffs = np.array([unpack(">6d", data[4 + 48 * p: 4 + 48 * (p + 1)]) for p in range(planes)], dtype=np.float64)
     cx, cy = unpack(">2d", data[4 + 48 * planes: 4 + 48 * planes + 16])
-    if prior is not None:
-        raise NotImplementedError("seeded (prior) warps are evaluated with compute_offset_remapping_table; "
-                                  "the fused in-place path takes no prior yet")
     if image.dtype != np.float32 or not image.flags.c_contiguous:
         raise ValueError("apply_opcode_3_warp works in place on a C-contiguous float32 (H, W, 3) image")
     H, W, _ = image.shape
-    _lib.check(_lib.lib().pysp_warp_rectilinear_f32(_lib.default_context().handle, _lib.ptr(image), H, W,
-                                                    coeffs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), planes, cx, cy, scale))
+    cptr = coeffs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    if prior is None:      # table evaluated inside the remap kernel, never materialised
+        _lib.check(_lib.lib().pysp_warp_rectilinear_f32(_lib.default_context().handle, _lib.ptr(image), H, W, cptr, planes, cx, cy, scale))
+    else:                  # seeded tables (compute_offset_remapping_table) from the prior mapping
+        pr = np.ascontiguousarray(prior, dtype=np.float32)
+        _lib.check(_lib.lib().pysp_warp_rectilinear_prior_f32(_lib.default_context().handle, _lib.ptr(image), H, W, cptr, planes, cx, cy, scale, _lib.ptr(pr)))
     return True
 
 

@@ -308,6 +308,13 @@ def main():
         blob = struct.pack(">I", 2) + struct.pack(">IIII", 9, 1, 1, 4) + b"\0\0\0\0" + struct.pack(">IIII", 1, 1, 0, len(payload)) + payload
         warped = img.copy()
         apply_opcode_3_warp(warped, blob)
+        from pySP.dng_warp_corr.chan_distortion_corr import stack_warp_prior
+        pr_r = compute_remapping_table(1.0, 0.004, 0.0, 0.0, 0.0, 0.0, img.shape[1], img.shape[0], 0.5, 0.5, 1.0)
+        prior = stack_warp_prior(img, pr_r, None, None)
+        warped_prior = img.copy()
+        apply_opcode_3_warp(warped_prior, blob, prior=prior)
+        save("g10_warp_prior", {"ref": "dng_warp_corr/chan_distortion_corr.py:11-41,88-97", "cv2_restated": True, "native": "oracle/_ref"},
+             image=img, blob=np.frombuffer(blob, dtype=np.uint8), prior=prior, warped=warped_prior)
         save("g10_warp_apply", {"ref": "dng_warp_corr/chan_distortion_corr.py:43-121", "cv2_restated": True, "native": "oracle/_ref"},
              image=img, blob=np.frombuffer(blob, dtype=np.uint8), coeffs=np.array(coeffs), centre=np.array([0.5, 0.5]), warped=warped)
     finally:

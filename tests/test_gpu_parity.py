@@ -590,3 +590,25 @@ def test_fuse_raw_sixteen_exposures(orc, wbobj):
     assert np.array_equal(hdr.sensor_scaled, ref) and np.array_equal(cnt, refc)
     with pytest.raises(ValueError):
         fuse_exposures_to_raw([_raw(frames[0], wbobj, ev=9.0)] * 17)
+
+
+def test_warp_with_prior_and_generic_remap(orc):
+    """Seeded tables (prior mapping) through apply_opcode_3_warp, and the restated cv2.remap entry point itself."""
+    import ctypes
+    from pysp_amd import _lib
+    from pysp_amd.dng_warp_corr import apply_opcode_3_warp, stack_warp_prior
+    d, _ = load_golden("g10_warp_prior")
+    img = d["image"].copy()
+    apply_opcode_3_warp(img, d["blob"].tobytes(), prior=d["prior"])
+    diff = np.abs(img - d["warped"])
+    assert np.mean(diff > 0) < 5e-3 and diff.max() < 5e-2          # same coordinate-rounding caveat as the unseeded path
+    ident = stack_warp_prior(d["image"], None, None, None)
+    assert ident.shape == d["image"].shape + (2,) and np.array_equal(ident[..., 0, 0][0], np.arange(d["image"].shape[1], dtype=np.float32))
+    rng = np.random.default_rng(6)
+    src = rng.random((61, 83), dtype=np.float32)
+    yy, xx = np.mgrid[0:61, 0:83].astype(np.float32)
+    mx = (xx + rng.normal(0, 2.0, xx.shape)).astype(np.float32); my = (yy + rng.normal(0, 2.0, yy.shape)).astype(np.float32)
+    mx = np.clip(mx, 0, 82).astype(np.float32); my = np.clip(my, 0, 60).astype(np.float32)
+    out = np.empty_like(src)
+    _lib.check(_lib.lib().pysp_remap_lanczos4_f32(_lib.default_context().handle, _lib.ptr(src), 61, 83, _lib.ptr(mx), _lib.ptr(my), _lib.ptr(out)))
+    assert np.array_equal(out, orc.remap_lanczos4(src, mx, my))          # explicit maps: bit-exact

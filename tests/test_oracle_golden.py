@@ -147,3 +147,20 @@ def test_g11_cleanup(orc):
     assert np.array_equal(orc.flat_field(d["bayer"], d["flat"]), d["corrected"], equal_nan=True)
     assert np.array_equal(orc.flat_field(d["bayer"], d["flat"], True), d["corrected_clamped"], equal_nan=True)
     assert np.array_equal(orc.flat_field(d["bayer"], np.zeros_like(d["flat"])), d["corrected_zero_flat"], equal_nan=True)
+
+
+def test_g10_warp_prior(orc):
+    """Seeded path: table from the prior (oracle warp_table with seed), clip, restated Lanczos remap, per plane."""
+    d, _ = load_golden("g10_warp_prior")
+    import struct
+    blob = d["blob"].tobytes()
+    payload = blob[4 + 16 + 4 + 16:]
+    planes = struct.unpack(">I", payload[:4])[0]
+    coeffs = [struct.unpack(">6d", payload[4 + 48 * p: 4 + 48 * (p + 1)]) for p in range(planes)]
+    cx, cy = struct.unpack(">2d", payload[4 + 48 * planes: 4 + 48 * planes + 16])
+    img = d["image"]; H, W, _ = img.shape
+    out = np.empty_like(img)
+    for c, k in enumerate(coeffs):
+        tab = orc.warp_table(*k, W, H, cx, cy, 1.0, seed=np.ascontiguousarray(d["prior"][:, :, c, :]))
+        out[..., c] = orc.remap_lanczos4(np.ascontiguousarray(img[..., c]), np.clip(tab[..., 0], 0, W - 1), np.clip(tab[..., 1], 0, H - 1))
+    assert np.array_equal(out, d["warped"])
