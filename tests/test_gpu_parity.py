@@ -612,3 +612,29 @@ def test_warp_with_prior_and_generic_remap(orc):
     out = np.empty_like(src)
     _lib.check(_lib.lib().pysp_remap_lanczos4_f32(_lib.default_context().handle, _lib.ptr(src), 61, 83, _lib.ptr(mx), _lib.ptr(my), _lib.ptr(out)))
     assert np.array_equal(out, orc.remap_lanczos4(src, mx, my))          # explicit maps: bit-exact
+
+
+def test_wb_undo_apply_and_clean_xyz(orc, wbobj):
+    """image_base.py:45-60 and transform.py:55-74 against the NumPy expressions they stand for."""
+    from pysp_amd.base_types.image_base import RawDemosaicData
+    from pysp_amd.colorize.rgb_space import LinRgbColorspace
+    from pysp_amd.colorize.transform import cam_to_clean_xyz, clip_rgb
+    rng = np.random.default_rng(13)
+    img = (rng.random((45, 67, 3), dtype=np.float32) * 1.3 - 0.1).astype(np.float32)
+    coeff = (1.0 / MULT).astype(np.float32)
+    d = RawDemosaicData(img.copy(), coeff)
+    d.mat_xyz = wbobj.get_matrix(); d.current_ev = 10.0
+    d.wb_undo()
+    undone = (img.astype(np.float64) / coeff[:3]).astype(np.float32)
+    assert np.array_equal(d.image, undone) and not d._wb_applied
+    d.wb_undo()                                           # second undo is a no-op
+    assert np.array_equal(d.image, undone)
+    d.wb_apply()
+    assert np.array_equal(d.image, (undone * coeff[:3]).astype(np.float32)) and d._wb_applied
+    assert np.array_equal(clip_rgb(img), np.clip(img, 0, 1))
+    # cam_to_clean_xyz = detinted REC2020 working RGB, then that space's RGB->XYZ (both float64 dots)
+    from pysp_amd.colorize.transform import final_matrix
+    M2020 = final_matrix(wbobj.get_matrix(), LinRgbColorspace.REC2020)
+    work = orc.cam_to_rgb(img, M2020, True)
+    ref = orc.cam_to_rgb(work, LinRgbColorspace.REC2020.mat_to_xyz(), False)
+    assert np.array_equal(cam_to_clean_xyz(img, wbobj.get_matrix()), ref)
