@@ -50,6 +50,12 @@ int pysp_device_count(void);
  * borrowed from the caller (e.g. torch.cuda.current_stream().cuda_stream). */
 pysp_ctx *pysp_ctx_create(int device, void *stream);
 void pysp_ctx_destroy(pysp_ctx *ctx);
+
+/* The two lookup tables of the restated float32 RGB->Lab used by the AHD homogeneity vote (replaces the
+ * table-driven float path of cv2.cvtColor(COLOR_RGB2LAB) called at debayer/ahd.py:58,62): dec receives
+ * 321x4 floats (sRGB decode, v in [2^-5,1]), cb 257x4 floats (cube root, t in [2^-7,2)).  Host only, needs no
+ * GPU; exported so that tests can compare the tables with the CPU oracle's bit for bit. */
+int pysp_lab_tables(float *dec, float *cb);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
  * the context's stream; waits for completion). */

@@ -164,6 +164,11 @@ def rgb2lab(rgb: np.ndarray) -> np.ndarray:
     return out
 
 
+def lab_tables():
+    dec = np.empty((321, 4), np.float32); cb = np.empty((257, 4), np.float32)
+    lib().orc_lab_tables(_p(dec), _p(cb)); return dec, cb
+
+
 def lab_pow24(u):
     a = _f32(u); out = np.empty_like(a)
     lib().orc_lab_pow24(_p(a), ctypes.c_size_t(a.size), _p(out)); return out

@@ -112,36 +112,64 @@ int orc_bayer_normalize_u16(const uint16_t *bayer, int H, int W, const float bla
  * Restated cv2.cvtColor(COLOR_RGB2LAB) for float32 (call sites ahd.py:58,62).  UNPINNED.
  * Semantics kept from OpenCV: input is treated as gamma-encoded sRGB, clipped to [0,1], decoded,
  * converted with the D65-normalised sRGB->XYZ matrix, then CIELab with the 0.008856 / 7.787 /
- * 903.3 constants; L in [0,100].  pow(.,2.4) and cbrt are our own deterministic routines built
- * from +,*,fmaf and integer ops only, so that the HIP kernel can reproduce them bit for bit:
- *   rfifth(u) ~ u^(-1/5): integer seed 0x4c2bc000 - int(float(bits)*0.2f), 3 Newton steps
- *   rcbrt(x)  ~ x^(-1/3): integer seed 0x54a24000 - int(float(bits)*(1/3)f), 3 Newton steps
- * measured max relative error: pow 7.3e-7, cbrt 4.3e-7 (tests/test_oracle_primitives.py). */
+ * 903.3 constants; L in [0,100].  Like OpenCV's float path, the two transcendental pieces (the
+ * ((v+0.055)/1.055)^2.4 decode and the cube root) are table driven -- OpenCV interpolates 1024-knot
+ * cubic splines (sRGBGammaTab, LabCbrtTab); this restatement uses float-exponent-indexed tables of
+ * quadratic segments, 64 per octave of v over [2^-5, 1] (321 entries) and 32 per octave of t over
+ * [2^-7, 2) (257 entries):
+ *     i = (bits(x) - bits(lo)) >> S ;  s = x - float(bits(x) with the low S bits cleared) (exact) ;
+ *     f(x) ~ fmaf(fmaf(c_i, s, b_i), s, a_i)
+ * with a, b, c the float32 casts of the parabola through f at the segment's ends and midpoint,
+ * evaluated in float64 (libm pow / cbrt).  Max relative error 1.3e-7 / 1.9e-7
+ * (tests/test_oracle_primitives.py); only +,*,fmaf and integer ops at run time, so the HIP kernel
+ * reproduces it bit for bit from identical tables (tests/test_abi_cpu.py compares the tables). */
 static inline float f_from_bits(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int32_t bits_from_f(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
 
-static inline float lab_pow24(float u) { /* u in (0.09, 1] */
-    float t = f_from_bits(0x4c2bc000 - (int32_t)((float)bits_from_f(u) * 0.2f));
-    float c = u * -0.2f;
-    for (int k = 0; k < 3; k++) {
-        float t2 = t * t, t4 = t2 * t2, t5 = t4 * t;
-        t = t * fmaf(c, t5, 1.2f);
+#define LAB_DEC_NB 6
+#define LAB_DEC_LOEXP (-5)
+#define LAB_DEC_N (5 * (1 << LAB_DEC_NB) + 1)
+#define LAB_CB_NB 5
+#define LAB_CB_LOEXP (-7)
+#define LAB_CB_N (8 * (1 << LAB_CB_NB) + 1)
+static float lab_dec_tab[LAB_DEC_N][4], lab_cb_tab[LAB_CB_N][4];
+static double lab_dec_fn(double v) { return pow((v + 0.055) / 1.055, 2.4); }
+static double lab_cb_fn(double t) { return cbrt(t); }
+static void lab_build(float (*tab)[4], int n, int nb, int loexp, double (*fn)(double)) {
+    int32_t b0 = bits_from_f(ldexpf(1.0f, loexp));
+    int s = 23 - nb;
+    for (int i = 0; i < n; i++) {
+        double x0 = (double)f_from_bits(b0 + (int32_t)((uint32_t)i << s));
+        double x1 = (double)f_from_bits(b0 + (int32_t)((uint32_t)(i + 1) << s));
+        double h = x1 - x0, g0 = fn(x0), gm = fn(x0 + 0.5 * h), g1 = fn(x1);
+        tab[i][0] = (float)g0;
+        tab[i][1] = (float)((-3.0 * g0 + 4.0 * gm - g1) / h);
+        tab[i][2] = (float)((2.0 * g0 - 4.0 * gm + 2.0 * g1) / (h * h));
+        tab[i][3] = 0.0f;
     }
-    float w = u * t;
-    return (w * w) * w;
 }
-static inline float lab_cbrt(float x) { /* x in (0.008856, ~1.1] */
-    float t = f_from_bits(0x54a24000 - (int32_t)((float)bits_from_f(x) * 0.33333334f));
-    float c = x * -0.33333334f;
-    for (int k = 0; k < 3; k++) {
-        float t3 = (t * t) * t;
-        t = t * fmaf(c, t3, 1.3333334f);
-    }
-    return x * (t * t);
+__attribute__((constructor)) static void lab_tables_init(void) {
+    lab_build(lab_dec_tab, LAB_DEC_N, LAB_DEC_NB, LAB_DEC_LOEXP, lab_dec_fn);
+    lab_build(lab_cb_tab, LAB_CB_N, LAB_CB_NB, LAB_CB_LOEXP, lab_cb_fn);
 }
+static inline float lab_lut(float (*tab)[4], int nb, int loexp, float x) {
+    int s = 23 - nb;
+    int32_t bits = bits_from_f(x), b0 = bits_from_f(ldexpf(1.0f, loexp));
+    int idx = (bits - b0) >> s;
+    float x0 = f_from_bits(bits & ~((1 << s) - 1));
+    float fr = x - x0;
+    return fmaf(fmaf(tab[idx][2], fr, tab[idx][1]), fr, tab[idx][0]);
+}
+static inline float lab_pow24(float v) { return lab_lut(lab_dec_tab, LAB_DEC_NB, LAB_DEC_LOEXP, v); }   /* v in (0.04045, 1]: ((v+0.055)/1.055)^2.4 */
+static inline float lab_cbrt(float x) { return lab_lut(lab_cb_tab, LAB_CB_NB, LAB_CB_LOEXP, x); }        /* x in (0.008856, 2) */
 static inline float lab_decode(float v) {
     v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); /* OpenCV clips the float input to [0,1] */
-    return v <= 0.04045f ? v * 0.07739938f /* 1/12.92 */ : lab_pow24((v + 0.055f) * 0.9478673f /* 1/1.055 */);
+    return v <= 0.04045f ? v * 0.07739938f /* 1/12.92 */ : lab_pow24(v);
+}
+int orc_lab_tables(float *dec /* LAB_DEC_N*4 */, float *cb /* LAB_CB_N*4 */) {
+    memcpy(dec, lab_dec_tab, sizeof(lab_dec_tab));
+    memcpy(cb, lab_cb_tab, sizeof(lab_cb_tab));
+    return ORC_OK;
 }
 /* sRGB(D65) -> XYZ rows divided by the D65 white (0.950456, 1, 1.088754), as float32 */
 #define LAB_C0 0.43395275f
@@ -170,7 +198,7 @@ int orc_rgb2lab(const float *rgb, size_t npx, float *lab) {
         rgb2lab_px(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], &lab[3 * i], &lab[3 * i + 1], &lab[3 * i + 2]);
     return ORC_OK;
 }
-int orc_lab_pow24(const float *u, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = lab_pow24(u[i]); return ORC_OK; }
+int orc_lab_pow24(const float *v, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = lab_pow24(v[i]); return ORC_OK; }
 int orc_lab_cbrt(const float *x, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = lab_cbrt(x[i]); return ORC_OK; }
 
 /* ------------------------------------------------------------------------------------------

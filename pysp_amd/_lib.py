@@ -35,6 +35,7 @@ _SIGNATURES = {
     "pysp_ctx_create": (_vp, [_int, _vp]),
     "pysp_ctx_destroy": (None, [_vp]),
     "pysp_ctx_sync": (_int, [_vp]),
+    "pysp_lab_tables": (_int, [_f32p, _f32p]),
     "pysp_ctx_last_kernel_ms": (_int, [_vp, _f32p]),
     "pysp_ctx_set_kernel_timing": (_int, [_vp, _int]),
     "pysp_ctx_kernel_times": (_int, [_vp, _int, _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_int)]),

@@ -11,6 +11,8 @@
 #include "../../include/pysp_hip.h"
 #include "kernels.h"
 #include "demosaic_common.h"
+#include "lab_tables.h"
+#include <math.h>
 
 namespace {
 
@@ -55,6 +57,7 @@ struct pysp_ctx {
     void* slot[NSLOT] = {};
     size_t cap[NSLOT] = {};
     float* lanczos = nullptr;
+    float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
     Timeline tl;
 
     int reserve(int i, size_t bytes, void** out) {
@@ -79,6 +82,37 @@ struct pysp_ctx {
 #define RESERVE(ctx, i, bytes, ptr)                                      \
     do { void* _p; int _r = (ctx)->reserve((i), (bytes), &_p); if (_r) return _r; (ptr) = reinterpret_cast<decltype(ptr)>(_p); } while (0)
 
+// Tables of lab_tables.h.  Segment i of a table starts at the float whose bits are bits(2^LOEXP) + (i << (23-NB)).
+namespace {
+template <typename F>
+void fill_segments(float* out, int count, int nb, int loexp, F f) {
+    const int shift = 23 - nb;
+    const uint32_t first = (uint32_t)(127 + loexp) << 23;
+    auto knot = [&](int i) { uint32_t u = first + ((uint32_t)i << shift); float x; memcpy(&x, &u, 4); return (double)x; };
+    for (int i = 0; i < count; i++, out += 4) {
+        const double lo = knot(i), hi = knot(i + 1), w = hi - lo;
+        const double f0 = f(lo), fm = f(lo + 0.5 * w), f1 = f(hi);
+        out[0] = (float)f0;
+        out[1] = (float)((-3.0 * f0 + 4.0 * fm - f1) / w);
+        out[2] = (float)((2.0 * f0 - 4.0 * fm + 2.0 * f1) / (w * w));
+        out[3] = 0.0f;
+    }
+}
+}  // namespace
+void host_lab_tables(float* dec, float* cb) {
+    fill_segments(dec, LAB_DEC_N, LAB_DEC_NB, LAB_DEC_LOEXP, [](double v) { return pow((v + 0.055) / 1.055, 2.4); });
+    fill_segments(cb, LAB_CB_N, LAB_CB_NB, LAB_CB_LOEXP, [](double t) { return cbrt(t); });
+}
+void host_lab_slots(float* slots) {
+    std::vector<float> dec(4 * LAB_DEC_N), cb(4 * LAB_CB_N);
+    host_lab_tables(dec.data(), cb.data());
+    memset(slots, 0, sizeof(float) * 4 * LAB_SLOTS);
+    for (int i = 0; i < LAB_DEC_N; i++)
+        memcpy(slots + 4 * ((((127 + LAB_DEC_LOEXP) << LAB_DEC_NB) + i) & (LAB_DEC_SLOTS - 1)), &dec[4 * i], 16);
+    for (int i = 0; i < LAB_CB_SLOTS; i++)
+        memcpy(slots + 4 * (LAB_DEC_SLOTS + ((((127 + LAB_CB_LOEXP) << LAB_CB_NB) + i) & (LAB_CB_SLOTS - 1))), &cb[4 * i], 16);
+}
+
 extern "C" {
 
 int pysp_abi_version(void) { return PYSP_ABI_VERSION; }
@@ -88,6 +122,12 @@ int pysp_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int pysp_lab_tables(float* dec, float* cb) {
+    if (!dec || !cb) return fail(PYSP_EBADARG, "pysp_lab_tables: null output");
+    host_lab_tables(dec, cb);
+    return PYSP_OK;
 }
 
 pysp_ctx* pysp_ctx_create(int device, void* stream) {
@@ -110,6 +150,10 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
     host_lanczos4_table(tab);
     if (hipMalloc(reinterpret_cast<void**>(&c->lanczos), sizeof(tab)) != hipSuccess ||
         hipMemcpy(c->lanczos, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "lanczos table upload failed"); pysp_ctx_destroy(c); return nullptr; }
+    std::vector<float> lt(4 * LAB_SLOTS);
+    host_lab_slots(lt.data());
+    if (hipMalloc(reinterpret_cast<void**>(&c->labtab), lt.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(c->labtab, lt.data(), lt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "Lab table upload failed"); pysp_ctx_destroy(c); return nullptr; }
     return c;
 }
 
@@ -119,6 +163,7 @@ void pysp_ctx_destroy(pysp_ctx* c) {
     if (c->stream) { e = hipStreamSynchronize(c->stream); (void)e; }
     for (int i = 0; i < pysp_ctx::NSLOT; i++) if (c->slot[i]) { e = hipFree(c->slot[i]); (void)e; }
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
+    if (c->labtab) { e = hipFree(c->labtab); (void)e; }
     for (int i = 0; i < 2 * Timeline::MAXK; i++) if (c->tl.ev[i]) { e = hipEventDestroy(c->tl.ev[i]); (void)e; }
     if (c->ev0) { e = hipEventDestroy(c->ev0); (void)e; }
     if (c->ev1) { e = hipEventDestroy(c->ev1); (void)e; }
@@ -324,7 +369,7 @@ static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, c
         size_t bytes = (size_t)H * W * 12;
         if (stages >= 1) RESERVE(ctx, S_TMP0, bytes, t0);
         if (stages >= 2) RESERVE(ctx, S_TMP1, bytes, t1);
-        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, &ctx->tl));
+        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, &ctx->tl));
     } else if (quality == PYSP_QUALITY_FAST) {
         LAUNCH_TRY(launch_eag(ctx->stream, src, H, W, wb, M, tail, d_out, &ctx->tl));
     } else if (quality == PYSP_QUALITY_DRAFT) {

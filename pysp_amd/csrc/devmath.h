@@ -48,45 +48,39 @@ DEVI float ccm_row(const double* m, float r, float g, float b) {
 }
 
 // ---- restated cv2.cvtColor(RGB2LAB) float32 (ahd.py:58,62); bit-identical to oracle rgb2lab_px ----
-DEVI float lab_pow24(float u) {
-    float t = __int_as_float(0x4c2bc000 - (int)((float)__float_as_int(u) * 0.2f));
-    float c = u * -0.2f;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float t2 = t * t, t4 = t2 * t2, t5 = t4 * t;
-        t = t * __builtin_fmaf(c, t5, 1.2f);
-    }
-    float w = u * t;
-    return (w * w) * w;
+// The sRGB decode ((v+0.055)/1.055)^2.4 and the cube root come from tables of quadratic segments indexed by
+// the float's exponent and top mantissa bits (64 segments per octave over [2^-5,1], 32 per octave over
+// [2^-7,2)); api.cpp builds them once per context (lab_tables.h) and the AHD kernel keeps a copy in LDS.
+// The LDS copy is laid out so that the slot is a plain bit field of the float: slot = (bits >> S) & (SLOTS-1)
+// (LAB_*_SLOTS in lab_tables.h), which makes every bit pattern -- also the ones whose lookup is discarded by
+// the range select, and NaN -- address the table itself.  A lookup is then shift, and (address), and, sub
+// (exact offset inside the segment), one 12-byte LDS read and two FMAs.
+#include "lab_tables.h"
+struct LabTab { const float4* dec; const float4* cb; };
+template <int NB, int SLOTS>
+DEVI float lab_lut(const float4* tab, float x) {
+    constexpr int S = 23 - NB;
+    static_assert(S > 4, "the byte offset is taken with one shift");
+    int bits = __float_as_int(x);
+    float4 e = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + ((bits >> (S - 4)) & ((SLOTS - 1) << 4)));
+    float fr = x - __int_as_float(bits & ~((1 << S) - 1));
+    return __builtin_fmaf(__builtin_fmaf(e.z, fr, e.y), fr, e.x);
 }
-DEVI float lab_cbrt(float x) {
-    float t = __int_as_float(0x54a24000 - (int)((float)__float_as_int(x) * 0.33333334f));
-    float c = x * -0.33333334f;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float t3 = (t * t) * t;
-        t = t * __builtin_fmaf(c, t3, 1.3333334f);
-    }
-    return x * (t * t);
-}
-DEVI float lab_decode(float v) {
+DEVI float lab_decode(LabTab t, float v) {
     v = clip01(v);
-    // both sides are evaluated (no divergence).  v >= 0 after the clip, so u >= 0.052 and the Newton
-    // iteration stays finite even where its result is discarded.
-    float u = (v + 0.055f) * 0.9478673f;
-    float p = lab_pow24(u);
+    float p = lab_lut<LAB_DEC_NB, LAB_DEC_SLOTS>(t.dec, v);   // both sides are evaluated (no divergence)
     return v <= 0.04045f ? v * 0.07739938f : p;
 }
-DEVI float lab_f(float t) {
-    float c = lab_cbrt(t);   // for t <= 0.008856 the value (possibly inf/NaN at t = 0) is discarded by the select
+DEVI float lab_f(LabTab tb, float t) {
+    float c = lab_lut<LAB_CB_NB, LAB_CB_SLOTS>(tb.cb, t);
     return t > 0.008856f ? c : __builtin_fmaf(7.787f, t, 0.13793103f);
 }
-DEVI void rgb2lab_px(float R, float G, float B, float& L, float& a, float& b) {
-    R = lab_decode(R); G = lab_decode(G); B = lab_decode(B);
+DEVI void rgb2lab_px(LabTab t, float R, float G, float B, float& L, float& a, float& b) {
+    R = lab_decode(t, R); G = lab_decode(t, G); B = lab_decode(t, B);
     float X = __builtin_fmaf(B, 0.18982783f, __builtin_fmaf(G, 0.37621942f, R * 0.43395275f));
     float Y = __builtin_fmaf(B, 0.072169f, __builtin_fmaf(G, 0.71516f, R * 0.212671f));
     float Z = __builtin_fmaf(B, 0.87276554f, __builtin_fmaf(G, 0.109476522f, R * 0.017757915f));
-    float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
+    float fx = lab_f(t, X), fy = lab_f(t, Y), fz = lab_f(t, Z);
     L = Y > 0.008856f ? __builtin_fmaf(116.0f, fy, -16.0f) : 903.3f * Y;
     a = 500.0f * (fx - fy);
     b = 200.0f * (fy - fz);

@@ -42,16 +42,16 @@ enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
 enum { Q_GHR = 0, Q_GHB, Q_DHR, Q_DHB, Q_GVR, Q_GVB, Q_DVR, Q_DVB };   // direction-major
 
 // ahd.py:32-62: second white balance, CCM without clip, (HDR: luma + x/(1+x)), Lab
-DEVI void homog_lab(float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, float& A, float& Bq) {
+DEVI void homog_lab(LabTab lt, float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, float& A, float& Bq) {
     float rr = r * wb[0], gg = g * wb[1], bb = b * wb[2];
     float sr = ccm_row(M, rr, gg, bb), sg = ccm_row(M + 3, rr, gg, bb), sb = ccm_row(M + 6, rr, gg, bb);
     if (hdr) {
         float luma = 0.2126f * sr + 0.7152f * sg + 0.0722f * sb;
         sr = sr / (1.0f + sr); sg = sg / (1.0f + sg); sb = sb / (1.0f + sb);
-        rgb2lab_px(sr, sg, sb, L, A, Bq);
+        rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
         L = luma;
     } else {
-        rgb2lab_px(sr, sg, sb, L, A, Bq);
+        rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
     }
 }
 
@@ -117,6 +117,7 @@ static_assert(12 * TQX * TQY <= 4 * MWY * MWX + 4 * GY * GX, "rgb_h stash must f
 struct AhdParams {
     MosaicSrc src;
     float* out;          // (H,W,3)
+    const float4* labtab; // LAB_SLOTS entries (lab_tables.h), copied to LDS by every workgroup
     int H, W;
     float wb[3];
     int hdr;
@@ -135,6 +136,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     float* const rgbh_lds = planes;                  // [12][TQY*TQX], needs 12*420 floats <= 4*MWY*MWX + 4*GY*GX
     __shared__ __attribute__((aligned(16))) float lab[3 * LPR * LPS];   // 31.9 KB, one direction at a time
     __shared__ __attribute__((aligned(16))) unsigned short vmap[MPR * MPS];   // 4.6 KB, votes: h | v << 8
+    __shared__ float4 s_labtab[LAB_SLOTS];                                  // 12 KB
+    const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
 
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
@@ -145,7 +148,12 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     // One 8-byte load per quad row; a thread's loads are all issued before its first LDS store.
     {
         constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT_A - 1) / NT_A;
+        static_assert(LAB_SLOTS % NT_A == 0, "table copy assumes whole rounds");
+        constexpr int NTAB = LAB_SLOTS / NT_A;
         float2 tmp[NL];
+        float4 ttab[NTAB];
+#pragma unroll
+        for (int k = 0; k < NTAB; k++) ttab[k] = p.labtab[tid + k * NT_A];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             int idx = tid + k * NT_A;
@@ -165,6 +173,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
                 mw[((dy ? P_B : P_G1) * MWY + my) * MWX + mx] = tmp[k].y * (dy ? p.wb[2] : p.wb[1]);
             }
         }
+#pragma unroll
+        for (int k = 0; k < NTAB; k++) s_labtab[tid + k * NT_A] = ttab[k];
     }
     __syncthreads();
 
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                homog_lab(rr[k], gg[k], bb[k], p.wb, M, p.hdr, labq[k][0], labq[k][1], labq[k][2]);
+                homog_lab(lt, rr[k], gg[k], bb[k], p.wb, M, p.hdr, labq[k][0], labq[k][1], labq[k][2]);
                 rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
                 __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
             }
@@ -485,8 +495,9 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
 
 // ------------------------------------------------------------------------------------------------
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
-               int tail, float* d_out, float* d_tmp0, float* d_tmp1, Timeline* tl) {
+               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, Timeline* tl) {
     AhdParams a;
+    a.labtab = reinterpret_cast<const float4*>(d_labtab);
     a.src = src; a.H = H; a.W = W; a.hdr = hdr;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M[i];

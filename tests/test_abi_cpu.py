@@ -48,6 +48,17 @@ def test_product_never_imports_oracle():
     assert not bad, bad
 
 
+def test_lab_tables_match_oracle_bit_for_bit(orc):
+    # the product builds its Lab lookup tables on the host (csrc/api.cpp); the oracle builds its own copy
+    import ctypes
+    from pysp_amd import _lib
+    dec = np.empty((321, 4), np.float32); cb = np.empty((257, 4), np.float32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    assert _lib.lib().pysp_lab_tables(dec.ctypes.data_as(f32p), cb.ctypes.data_as(f32p)) == 0
+    odec, ocb = orc.lab_tables()
+    assert dec.tobytes() == odec.tobytes() and cb.tobytes() == ocb.tobytes()
+
+
 def test_final_matrix_matches_oracle_host_restatement(orc):
     from pysp_amd.colorize.transform import final_matrix
     from pysp_amd.wb_cct.helpers_cam_mat import MatXyzToCamera, xy_to_XYZ
