@@ -45,8 +45,8 @@ WORKLOADS = {
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
