@@ -165,6 +165,12 @@ int pysp_warp_rectilinear_prior_f32(pysp_ctx *ctx, float *image, int H, int W, c
 /* The restated cv2.remap(plane, mapx, mapy, INTER_LANCZOS4) itself (:94-97), maps as given (no clipping). */
 int pysp_remap_lanczos4_f32(pysp_ctx *ctx, const float *src, int H, int W, const float *mapx, const float *mapy, float *dst);
 int pysp_warp_rectilinear_dev(pysp_ctx *ctx, const float *d_in, float *d_out, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale);
+/* Band form for one frame sharded over several GPUs (BASELINE config 5): d_in and d_out address the whole
+ * (H,W,3) frame, only output rows [row0,row1) are produced; source rows outside pysp_warp_source_rows' range are never read. */
+int pysp_warp_rectilinear_rows_dev(pysp_ctx *ctx, const float *d_in, float *d_out, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale, int row0, int row1);
+/* Rows [*src_row0,*src_row1) of the source frame that the Lanczos footprints of output rows [row0,row1) touch (same
+ * coordinate arithmetic as the remap itself, reduced on the device): what a band has to receive from its peers. */
+int pysp_warp_source_rows(pysp_ctx *ctx, int H, int W, const double *coeffs, int planes, double cx_norm, double cy_norm, float scale, int row0, int row1, int *src_row0, int *src_row1);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ PYSP_OK, PYSP_EBADARG, PYSP_ENOTIMPL, PYSP_EHIP, PYSP_ENOMEM = 0, -1, -2, -3, -4
 QUALITY_DRAFT, QUALITY_FAST, QUALITY_BEST = 0, 1, 2
 
 _f32p = ctypes.POINTER(ctypes.c_float)
+_intp = ctypes.POINTER(ctypes.c_int)
 _f64p = ctypes.POINTER(ctypes.c_double)
 _u16p = ctypes.POINTER(ctypes.c_uint16)
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -69,6 +70,8 @@ _SIGNATURES = {
     "pysp_warp_rectilinear_prior_f32": (_int, [_vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt, _vp]),
     "pysp_remap_lanczos4_f32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp]),
     "pysp_warp_rectilinear_dev": (_int, [_vp, _vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt]),
+    "pysp_warp_rectilinear_rows_dev": (_int, [_vp, _vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt, _int, _int]),
+    "pysp_warp_source_rows": (_int, [_vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt, _int, _int, _intp, _intp]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -606,15 +606,37 @@ int pysp_warp_rectilinear_prior_f32(pysp_ctx* ctx, float* image, int H, int W, c
     TRY(d2h(ctx, image, d_out, n * 12));
     return pysp_ctx_sync(ctx);
 }
-int pysp_warp_rectilinear_dev(pysp_ctx* ctx, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale) {
+int pysp_warp_rectilinear_rows_dev(pysp_ctx* ctx, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale,
+                                   int row0, int row1) {
     CTX_ENTER(ctx);
     if (!d_in || !d_out || !coeffs || d_in == d_out) return fail(PYSP_EBADARG, "warp_rectilinear: null or aliased buffers");
     if (planes != 3 || H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_rectilinear: plane count %d does not match a 3-channel image", planes);
+    if (row0 < 0 || row1 > H || row0 >= row1) return fail(PYSP_EBADARG, "warp_rectilinear: rows [%d,%d) are not inside the %d-row frame", row0, row1, H);
     ctx->tic();
     ctx->tl.begin(ctx->stream, "k_warp_remap");
-    LAUNCH_TRY(launch_warp_remap(ctx->stream, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale, ctx->lanczos));
+    LAUNCH_TRY(launch_warp_remap(ctx->stream, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale, ctx->lanczos, row0, row1));
     ctx->tl.end(ctx->stream);
     ctx->toc();
+    return PYSP_OK;
+}
+int pysp_warp_rectilinear_dev(pysp_ctx* ctx, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale) {
+    return pysp_warp_rectilinear_rows_dev(ctx, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale, 0, H);
+}
+int pysp_warp_source_rows(pysp_ctx* ctx, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale, int row0, int row1,
+                          int* src_row0, int* src_row1) {
+    CTX_ENTER(ctx);
+    if (!coeffs || !src_row0 || !src_row1) return fail(PYSP_EBADARG, "warp_source_rows: null pointer");
+    if (planes != 3 || H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_source_rows: plane count %d does not match a 3-channel image", planes);
+    if (row0 < 0 || row1 > H || row0 >= row1) return fail(PYSP_EBADARG, "warp_source_rows: rows [%d,%d) are not inside the %d-row frame", row0, row1, H);
+    int* d_rows;
+    RESERVE(ctx, S_AUX, 2 * sizeof(int), d_rows);
+    LAUNCH_TRY(launch_warp_src_rows(ctx->stream, H, W, coeffs, planes, cx_norm, cy_norm, scale, row0, row1, d_rows));
+    int rows[2];
+    TRY(d2h(ctx, rows, d_rows, sizeof(rows)));
+    TRY(pysp_ctx_sync(ctx));
+    *src_row0 = rows[0] < 0 ? 0 : rows[0];                 // taps outside the image read the constant border, not a row
+    *src_row1 = (rows[1] >= H ? H - 1 : rows[1]) + 1;
+    if (*src_row1 <= *src_row0) { *src_row0 = 0; *src_row1 = 0; }
     return PYSP_OK;
 }
 int pysp_warp_rectilinear_f32(pysp_ctx* ctx, float* image, int H, int W, const double* coeffs, int planes, double cx_norm, double cy_norm, float scale) {

@@ -226,6 +226,7 @@ struct RemapParams {
     float* out;        // (H,W,3), must not alias in
     const float* tab;  // [32][8]
     int H, W;
+    int row0, row1;    // output rows [row0, row1) are produced (a band of the frame; the whole frame is 0, H)
     WarpCoef k[3];
     WarpGeom g;
     float scale;
@@ -245,7 +246,8 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     __shared__ int corner[3][4][2];          // per channel: source cell (ix, iy) of the block's four corner pixels
     const int tid = threadIdx.x;
     stab[tid] = p.tab[tid];
-    const int x = blockIdx.x * WBX + (tid & 63), y0 = blockIdx.y * WBY + (tid >> 6) * 2;
+    const int by0 = p.row0 + blockIdx.y * WBY;
+    const int x = blockIdx.x * WBX + (tid & 63), y0 = by0 + (tid >> 6) * 2;
     const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
     auto cell = [&](float mx, float my, int& fx, int& fy) {
         mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);       // np.clip, chan_distortion_corr.py:95-96
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     };
     if (tid < 12) {
         const int c = tid >> 2, k = tid & 3;
-        int cx = min(blockIdx.x * WBX + ((k & 1) ? WBX - 1 : 0), p.W - 1), cy = min(blockIdx.y * WBY + ((k & 2) ? WBY - 1 : 0), p.H - 1);
+        int cx = min(blockIdx.x * WBX + ((k & 1) ? WBX - 1 : 0), p.W - 1), cy = min(by0 + ((k & 2) ? WBY - 1 : 0), p.row1 - 1);
         float mx, my; int fx, fy;
         warp_px((float)cx, (float)cy, p.k[c], p.g, p.scale, mx, my);
         cell(mx, my, fx, fy);
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int y = y0 + j;
-        if (y >= p.H) break;
+        if (y >= p.row1) break;
         float res[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -381,17 +383,55 @@ int launch_remap_table(hipStream_t st, const float* src, int sstride, const floa
     return CHECK_LAUNCH();
 }
 
-int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
-                      double cyn, float scale, const float* d_lanczos_tab) {
-    if (planes != 3) return -1;
-    RemapParams p;
-    p.in = d_in; p.out = d_out; p.tab = d_lanczos_tab; p.H = H; p.W = W; p.scale = scale;
+// Source rows the Lanczos footprints of output rows [row0, row1) touch: the same coordinate evaluation as k_warp_remap,
+// reduced to a min / max source row over all pixels and channels.  rows[0] starts at INT_MAX, rows[1] at INT_MIN.
+__global__ void __launch_bounds__(256) k_warp_src_rows(RemapParams p, int* __restrict__ rows) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = p.row0 + blockIdx.y;
+    int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+    if (x < p.W && y < p.row1) {
+        const float ymax = (float)(p.H - 1);
+        WarpRad wr = warp_rad((float)x, (float)y, p.g);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float mx, my;
+            warp_poly((float)x, (float)y, wr, p.k[c], p.g, p.scale, mx, my);
+            my = my < 0.0f ? 0.0f : (my > ymax ? ymax : my);
+            int iy = ((int)rintf(my * 32.0f) >> 5) - 3;
+            lo = min(lo, iy); hi = max(hi, iy + 7);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMin(rows, lo); atomicMax(rows + 1, hi); }
+}
+
+static int fill_remap_params(RemapParams& p, int H, int W, const double* coeffs, int planes, double cxn, double cyn, float scale, int row0, int row1) {
+    if (planes != 3 || row0 < 0 || row1 > H || row0 >= row1) return -1;
+    p.H = H; p.W = W; p.scale = scale; p.row0 = row0; p.row1 = row1;
     for (int c = 0; c < 3; c++) {
         const double* k = coeffs + 6 * c;
         p.k[c] = {(float)k[0], (float)k[1], (float)k[2], (float)k[3], (float)k[4], (float)k[5]};
     }
     p.g = warp_geom(W, H, (float)cxn, (float)cyn);
-    dim3 grid((W + WBX - 1) / WBX, (H + WBY - 1) / WBY);
+    return 0;
+}
+int launch_warp_src_rows(hipStream_t st, int H, int W, const double* coeffs, int planes, double cxn, double cyn, float scale, int row0, int row1,
+                         int* d_rows) {
+    RemapParams p;
+    p.in = nullptr; p.out = nullptr; p.tab = nullptr;
+    if (fill_remap_params(p, H, W, coeffs, planes, cxn, cyn, scale, row0, row1)) return -1;
+    const int init[2] = {0x7fffffff, -0x7fffffff - 1};
+    if (hipMemcpyAsync(d_rows, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    dim3 grid((W + 255) / 256, row1 - row0);
+    hipLaunchKernelGGL(k_warp_src_rows, grid, dim3(256), 0, st, p, d_rows);
+    return CHECK_LAUNCH();
+}
+
+int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
+                      double cyn, float scale, const float* d_lanczos_tab, int row0, int row1) {
+    RemapParams p;
+    p.in = d_in; p.out = d_out; p.tab = d_lanczos_tab;
+    if (fill_remap_params(p, H, W, coeffs, planes, cxn, cyn, scale, row0, row1)) return -1;
+    dim3 grid((W + WBX - 1) / WBX, (row1 - row0 + WBY - 1) / WBY);
     hipLaunchKernelGGL(k_warp_remap, grid, dim3(256), 0, st, p);
     return CHECK_LAUNCH();
 }

@@ -54,7 +54,9 @@ int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* 
 int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
                       float cxn, float cyn, float scale, const float* d_seed, float* d_table);
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
-                      double cyn, float scale, const float* d_lanczos_tab);
+                      double cyn, float scale, const float* d_lanczos_tab, int row0, int row1);
+int launch_warp_src_rows(hipStream_t st, int H, int W, const double* coeffs, int planes, double cxn, double cyn, float scale, int row0, int row1,
+                         int* d_rows);
 int launch_remap_table(hipStream_t st, const float* src, int sstride, const float* mapx, const float* mapy, int mstride, const float* d_tab,
                        int H, int W, int do_clip, float* dst, int dstride);
 void host_lanczos4_table(float tab[256]);

@@ -1,9 +1,15 @@
-"""Frame-parallel sharding over the GPUs of one node.
+"""Sharding over the GPUs of one node.
 
-Frames (and HDR stacks) are independent, so the data path needs no collective: frame i goes to rank
-i mod world.  The only exchange is the shared parameter block (white-balance multipliers + final
-colour matrix), broadcast once per batch from the rank that owns the camera metadata -- 96 bytes,
+Frame-parallel: frames (and HDR stacks) are independent, so the data path needs no collective: frame i
+goes to rank i mod world.  The only exchange is the shared parameter block (white-balance multipliers +
+final colour matrix), broadcast once per batch from the rank that owns the camera metadata -- 96 bytes,
 latency bound; with backend "nccl" this is RCCL over xGMI, with "gloo" it runs on CPU (tests).
+
+Band-parallel (one very large frame, BASELINE config 5): rank b demosaics band b from host rows that
+already include the stencil halo (no GPU-to-GPU traffic), but the lens warp that follows reads source
+rows of other bands.  Those rows -- and only those, bounded on the device from the warp polynomial --
+are exchanged point to point (xGMI is a full mesh, so every pair has its own link); the first-cut
+alternative, an all-gather of all bands, is kept for comparison and as the fallback for extreme warps.
 """
 from __future__ import annotations
 
@@ -63,3 +69,125 @@ def band_ranges(H: int, n_bands: int, halo: int) -> List[Tuple[int, int, int, in
         y1 = 2 * (rows * (b + 1) // n_bands)
         out.append((y0, y1, max(0, y0 - halo), min(H, y1 + halo)))
     return out
+
+
+# ---- band-parallel: row exchange between the demosaic and the warp of one frame -------------------
+
+def plan_row_exchange(bands: Sequence[Tuple[int, int]], needs: Sequence[Tuple[int, int]]) -> List[Tuple[int, int, int, int]]:
+    """Transfers (src_rank, dst_rank, r0, r1): rank `src` owns output rows bands[src] = [y0, y1) of the debayered frame,
+    rank `dst` needs source rows needs[dst] = [s0, s1) for its warp band; every overlap with another rank's band is one
+    contiguous row block.  Deterministic order (by dst, then src) -- every rank derives the same plan."""
+    plan = []
+    for dst, (s0, s1) in enumerate(needs):
+        for src, (y0, y1) in enumerate(bands):
+            if src == dst:
+                continue
+            r0, r1 = max(s0, y0), min(s1, y1)
+            if r0 < r1:
+                plan.append((src, dst, r0, r1))
+    return plan
+
+
+def exchange_rows(full, plan: Sequence[Tuple[int, int, int, int]], rank: int, group=None, via_host: bool = False):
+    """Run `plan` on the whole-frame tensor `full` (rows first): sends this rank's rows, receives the others' in place.
+    One batch of point-to-point operations (RCCL send/recv over xGMI with backend "nccl").  `via_host` stages the
+    blocks through CPU tensors, which is what the gloo backend needs for device data (tests, one-GPU rehearsal)."""
+    import torch
+    import torch.distributed as dist
+    ops, landing = [], []
+    for src, dst, r0, r1 in plan:
+        if src == rank:
+            blk = full[r0:r1]
+            ops.append(dist.P2POp(dist.isend, blk.cpu() if via_host else blk, dst, group))
+        elif dst == rank:
+            if via_host:
+                buf = torch.empty(full[r0:r1].shape, dtype=full.dtype)
+                landing.append((buf, r0, r1))
+                ops.append(dist.P2POp(dist.irecv, buf, src, group))
+            else:
+                ops.append(dist.P2POp(dist.irecv, full[r0:r1], src, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for buf, r0, r1 in landing:
+        full[r0:r1].copy_(buf)
+    return full
+
+
+def allgather_bands(full, bands: Sequence[Tuple[int, int]], rank: int, group=None, via_host: bool = False):
+    """First-cut exchange: every rank ends up with the whole debayered frame.  Equal bands: one all-gather straight into
+    the frame buffer (band order = rank order = row order); ragged bands: one broadcast per band."""
+    import torch
+    import torch.distributed as dist
+    sizes = {y1 - y0 for y0, y1 in bands}
+    y0, y1 = bands[rank]
+    if len(sizes) == 1 and bands[0][0] == 0 and bands[-1][1] == full.shape[0]:
+        if via_host:
+            host = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(host, full[y0:y1].cpu(), group=group)
+            full.copy_(host)
+        else:
+            mine = full[y0:y1].clone()          # the output must not alias the input
+            dist.all_gather_into_tensor(full, mine, group=group)
+        return full
+    for b, (b0, b1) in enumerate(bands):
+        if via_host:
+            t = full[b0:b1].cpu()
+            dist.broadcast(t, src=b, group=group)
+            if b != rank:
+                full[b0:b1].copy_(t)
+        else:
+            dist.broadcast(full[b0:b1], src=b, group=group)
+    return full
+
+
+def ahd_halo_rows(stages: int) -> int:
+    """Rows of real neighbour data a band needs on each side for AHD with `stages` median post-process stages."""
+    return 8 + 4 * max(0, int(stages))
+
+
+def _settle(pipe) -> None:
+    """The library's kernels run on the pipeline's own stream, tensor copies and collectives on torch's: join both."""
+    pipe.sync()
+    if getattr(pipe.device, "type", "cpu") == "cuda":
+        pipe.torch.cuda.synchronize(pipe.device)
+
+
+def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0,
+                         rank: int = 0, world: int = 1, group=None, exchange: str = "needed", via_host: bool = False):
+    """BASELINE config 5 across `world` GPUs: AHD(stages) of band `rank` of the frame, row exchange, WarpRectilinear of
+    the same band (chan_distortion_corr.py:86-97 after debayer/ahd.py).  `pipe` is this rank's DevicePipeline.
+    Returns (y0, y1, band) with band = rows [y0, y1) of the warped (H,W,3) frame on the device; the rows are identical
+    to the same rows of `pipe.demosaic_warp` on the whole frame."""
+    from . import _lib
+    torch = pipe.torch
+    H, W = bayer_host.shape
+    bands4 = band_ranges(H, world, ahd_halo_rows(stages))
+    if len(bands4) != world:
+        raise ValueError(f"a {H}-row frame cannot be cut into {world} bands")
+    bands = [(b[0], b[1]) for b in bands4]
+    y0, y1, r0, r1 = bands4[rank]
+    sub = torch.from_numpy(np.ascontiguousarray(bayer_host[r0:r1])).to(pipe.device)
+    rgb = pipe.demosaic(sub, wb, M, _lib.QUALITY_BEST, False, stages)
+    full = torch.empty((H, W, 3), dtype=torch.float32, device=pipe.device)
+    full[y0:y1].copy_(rgb[y0 - r0:y1 - r0])
+    del rgb, sub
+    if world > 1:
+        import torch.distributed as dist
+        _settle(pipe)
+        if exchange == "needed":
+            s0, s1 = pipe.warp_source_rows(H, W, coeffs, centre, y0, y1, scale)
+            mine = torch.tensor([s0, s1], dtype=torch.int64, device="cpu" if via_host else pipe.device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            needs = [(int(t[0]), int(t[1])) for t in every]
+            exchange_rows(full, plan_row_exchange(bands, needs), rank, group, via_host)
+        elif exchange == "allgather":
+            allgather_bands(full, bands, rank, group, via_host)
+        else:
+            raise ValueError("exchange must be 'needed' or 'allgather'")
+        _settle(pipe)
+    out = torch.empty_like(full)
+    pipe.warp_rows(full, coeffs, centre, y0, y1, out, scale)
+    pipe.sync()
+    return y0, y1, out[y0:y1]

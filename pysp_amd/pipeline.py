@@ -121,6 +121,29 @@ class DevicePipeline:
                                                     cf.size // 6, float(centre[0]), float(centre[1]), float(scale)))
         return out
 
+    def warp_rows(self, rgb, coeffs, centre: Tuple[float, float], row0: int, row1: int, out, scale: float = 1.0):
+        """Output rows [row0, row1) of `warp` only; `rgb` and `out` are whole-frame (H,W,3) device buffers of which
+        only the rows `warp_source_rows` names need to hold valid data (one band of a frame sharded over GPUs)."""
+        if rgb.dtype != self.torch.float32 or rgb.dim() != 3 or rgb.shape[2] != 3 or not rgb.is_contiguous():
+            raise ValueError("expected a contiguous float32 (H, W, 3) image")
+        if out.shape != rgb.shape or out.dtype != rgb.dtype or not out.is_contiguous():
+            raise ValueError("out must be a whole-frame buffer like the input")
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1)
+        self._enter()
+        _lib.check(self.L.pysp_warp_rectilinear_rows_dev(self.ctx.handle, _dp(rgb), _dp(out), H, W, cf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                         cf.size // 6, float(centre[0]), float(centre[1]), float(scale), int(row0), int(row1)))
+        return out
+
+    def warp_source_rows(self, H: int, W: int, coeffs, centre: Tuple[float, float], row0: int, row1: int, scale: float = 1.0) -> Tuple[int, int]:
+        """Source rows [s0, s1) the warp of output rows [row0, row1) reads (device reduction of the same coordinates)."""
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64).reshape(-1)
+        s0, s1 = ctypes.c_int(0), ctypes.c_int(0)
+        self._enter()
+        _lib.check(self.L.pysp_warp_source_rows(self.ctx.handle, int(H), int(W), cf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), cf.size // 6,
+                                                float(centre[0]), float(centre[1]), float(scale), int(row0), int(row1), ctypes.byref(s0), ctypes.byref(s1)))
+        return s0.value, s1.value
+
     def demosaic_warp(self, bayer, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0):
         """BASELINE config 5 on one GPU: AHD(postprocess_stages) then per-channel WarpRectilinear."""
         rgb = self.demosaic(bayer, wb, M, _lib.QUALITY_BEST, False, stages)

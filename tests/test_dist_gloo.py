@@ -73,3 +73,136 @@ def test_band_ranges():
                 assert nxt[0] == y1
     with pytest.raises(ValueError):
         band_ranges(7, 2, 2)
+
+
+# ---- band-parallel (BASELINE config 5): row exchange between demosaic and warp -----------------------
+
+def test_plan_row_exchange():
+    from pysp_amd.multi_gpu import plan_row_exchange
+    bands = [(0, 10), (10, 20), (20, 30)]
+    needs = [(0, 13), (8, 22), (19, 30)]
+    plan = plan_row_exchange(bands, needs)
+    assert plan == [(1, 0, 10, 13), (0, 1, 8, 10), (2, 1, 20, 22), (1, 2, 19, 20)]
+    assert plan_row_exchange(bands, bands) == []                       # identity warp: nothing moves
+    assert plan_row_exchange(bands, [(0, 30)] * 3) == [(1, 0, 10, 20), (2, 0, 20, 30), (0, 1, 0, 10), (2, 1, 20, 30), (0, 2, 0, 10), (1, 2, 10, 20)]
+    assert plan_row_exchange(bands, [(0, 0), (0, 0), (25, 26)]) == []  # empty needs, needs inside the own band
+
+
+def _exchange_worker(rank, world, port, q, mode):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from pysp_amd.multi_gpu import allgather_bands, exchange_rows, plan_row_exchange
+        H, W = 24, 5
+        truth = torch.arange(H * W * 3, dtype=torch.float32).reshape(H, W, 3)
+        bands = [(0, 8), (8, 16), (16, 24)] if mode != "ragged" else [(0, 6), (6, 18), (18, 24)]
+        y0, y1 = bands[rank]
+        full = torch.full((H, W, 3), float("nan"))
+        full[y0:y1] = truth[y0:y1]
+        if mode == "needed":
+            needs = [(0, 11), (5, 17), (13, 24)]
+            exchange_rows(full, plan_row_exchange(bands, needs), rank, via_host=(rank % 2 == 0))   # both landing paths
+            s0, s1 = needs[rank]
+            lo, hi = min(s0, y0), max(s1, y1)
+            ok = bool(torch.equal(full[lo:hi], truth[lo:hi])) and bool(torch.isnan(full[:lo]).all()) and bool(torch.isnan(full[hi:]).all())
+        else:
+            allgather_bands(full, bands, rank, via_host=(mode == "ragged" and rank == 1))
+            ok = bool(torch.equal(full, truth))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["needed", "allgather", "ragged"])
+def test_row_exchange_world3(mode):
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True), (2, True)]
+
+
+class _OraclePipe:
+    """Stand-in for DevicePipeline with the CPU oracle as the compute: rehearses the orchestration of
+    demosaic_warp_banded (band cut, halo, exchange plan, row-limited warp) without a GPU."""
+    def __init__(self, orc):
+        import torch
+        self.torch, self.orc, self.device = torch, orc, torch.device("cpu")
+
+    def sync(self):
+        pass
+
+    def demosaic(self, bayer, wb, M, quality, hdr, stages):
+        return self.torch.from_numpy(self.orc.demosaic_ahd(bayer.numpy(), wb, M, hdr, stages))
+
+    def _cells(self, H, W, coeffs, centre, scale):
+        rows = []
+        for c in range(3):
+            k = [float(v) for v in np.asarray(coeffs, np.float64).reshape(3, 6)[c]]
+            tab = self.orc.warp_table(*k, W, H, float(centre[0]), float(centre[1]), float(scale))
+            my = np.clip(tab[..., 1], 0, H - 1)
+            rows.append((np.rint(my * np.float32(32)).astype(np.int64) >> 5) - 3)
+        return np.stack(rows)                                            # first tap row per channel and pixel
+
+    def warp_source_rows(self, H, W, coeffs, centre, row0, row1, scale=1.0):
+        iy = self._cells(H, W, coeffs, centre, scale)[:, row0:row1]
+        return max(0, int(iy.min())), min(H - 1, int(iy.max()) + 7) + 1
+
+    def warp_rows(self, rgb, coeffs, centre, row0, row1, out, scale=1.0):
+        res = self.orc.warp_rectilinear(rgb.numpy().copy(), coeffs, centre, scale)
+        out[row0:row1] = self.torch.from_numpy(res[row0:row1])
+        return out
+
+
+def _banded_worker(rank, world, port, q, exchange):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import oracle as orc
+        from pysp_amd import multi_gpu
+        from pysp_amd.colorize.transform import final_matrix
+        from pysp_amd.synth import default_wb, rggb_frame
+        import torch
+        H, W, stages = 96, 64, 1
+        bayer = rggb_frame(H, W, 1234)
+        wbobj = default_wb()
+        wb, M = wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix())
+        coeffs = np.array([[1.0, 0.05, 0.01, 0, 0, 0], [1.0, 0, 0, 0, 0, 0], [1.0, -0.05, 0.01, 0, 0.002, 0]])
+        real_empty = torch.empty
+        torch.empty = lambda *a, **k: real_empty(*a, **k).fill_(float("nan")) if k.get("dtype", None) == torch.float32 else real_empty(*a, **k)
+        try:
+            y0, y1, band = multi_gpu.demosaic_warp_banded(_OraclePipe(orc), bayer, wb, M, coeffs, (0.5, 0.5), stages=stages, rank=rank, world=world,
+                                                          exchange=exchange)
+        finally:
+            torch.empty = real_empty
+        ref = orc.warp_rectilinear(orc.demosaic_ahd(bayer, wb, M, False, stages), coeffs, (0.5, 0.5), 1.0)
+        q.put((rank, y0, y1, bool(np.array_equal(band.numpy(), ref[y0:y1]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["needed", "allgather"])
+def test_banded_demosaic_warp_world2_oracle_compute(exchange):
+    # rows a band does not need stay NaN in its frame buffer: the output must still equal the whole-frame result
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_banded_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 0, 48, True), (1, 48, 96, True)]

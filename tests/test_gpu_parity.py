@@ -638,3 +638,93 @@ def test_wb_undo_apply_and_clean_xyz(orc, wbobj):
     work = orc.cam_to_rgb(img, M2020, True)
     ref = orc.cam_to_rgb(work, LinRgbColorspace.REC2020.mat_to_xyz(), False)
     assert np.array_equal(cam_to_clean_xyz(img, wbobj.get_matrix()), ref)
+
+
+def test_warp_band_rows_and_source_row_bound(orc):
+    """Row-limited warp (one band of a frame sharded over GPUs): equals the whole-frame warp on its rows and reads
+    only the rows pysp_warp_source_rows names -- everything else in the source buffer is NaN here."""
+    import torch
+    from pysp_amd.dng_warp_corr.dng_warp_rectilinear_coords import compute_remapping_table
+    from pysp_amd.pipeline import DevicePipeline
+    pipe = DevicePipeline(0)
+    H, W = 300, 420
+    rng = np.random.default_rng(77)
+    rgb = torch.from_numpy(rng.random((H, W, 3), dtype=np.float32)).cuda()
+    coeffs = np.array([[1.0, 0.06, 0.01, 0.0, 0.001, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0, 0.0], [0.98, -0.05, 0.01, 0.0, 0.0, 0.002]])
+    centre = (0.5, 0.48)
+    whole = pipe.warp(rgb, coeffs, centre)
+    pipe.sync()
+    whole = whole.cpu().numpy()
+    for (y0, y1) in [(0, 100), (100, 196), (196, 300), (37, 38)]:
+        s0, s1 = pipe.warp_source_rows(H, W, coeffs, centre, y0, y1)
+        # the same bound from the product's own coordinate table (compute_remapping_table runs the same arithmetic)
+        first = []
+        for c in range(3):
+            tab = compute_remapping_table(*[float(v) for v in coeffs[c]], W, H, centre[0], centre[1], 1.0)
+            my = np.clip(tab[y0:y1, :, 1], 0, H - 1)
+            first.append((np.rint(my * np.float32(32)).astype(np.int64) >> 5) - 3)
+        first = np.stack(first)
+        assert (s0, s1) == (max(0, int(first.min())), min(H - 1, int(first.max()) + 7) + 1)
+        assert s0 <= y1 and s1 >= y0
+        poisoned = torch.full_like(rgb, float("nan"))
+        poisoned[s0:s1] = rgb[s0:s1]
+        out = torch.full_like(rgb, -1.0)
+        pipe.warp_rows(poisoned, coeffs, centre, y0, y1, out)
+        pipe.sync()
+        o = out.cpu().numpy()
+        assert np.array_equal(o[y0:y1], whole[y0:y1])
+        assert (o[:y0] == -1).all() and (o[y1:] == -1).all()         # rows outside the band are not written
+    with pytest.raises(ValueError):
+        pipe.warp_rows(rgb, coeffs, centre, 10, 10, torch.empty_like(rgb))
+    with pytest.raises(ValueError):
+        pipe.warp_source_rows(H, W, coeffs, centre, -2, 10)
+
+
+def _banded_gpu_worker(rank, world, port, q, exchange):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from pysp_amd import multi_gpu
+        from pysp_amd.colorize.transform import final_matrix
+        from pysp_amd.pipeline import DevicePipeline
+        from pysp_amd.synth import default_wb, rggb_frame
+        H, W, stages = 400, 512, 3
+        bayer = rggb_frame(H, W, 4321)
+        wbobj = default_wb()
+        wb, M = wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix())
+        coeffs = np.array([[1.0, 0.03, 0.002, 0, 0, 0], [1.0, 0, 0, 0, 0, 0], [1.0, -0.03, 0.002, 0, 0.001, 0]])
+        pipe = DevicePipeline(0)                                           # both ranks rehearse on the one GPU of the box
+        y0, y1, band = multi_gpu.demosaic_warp_banded(pipe, bayer, wb, M, coeffs, (0.5, 0.5), stages=stages, rank=rank, world=world,
+                                                      exchange=exchange, via_host=True)
+        ref = pipe.demosaic_warp(torch.from_numpy(bayer).cuda(), wb, M, coeffs, (0.5, 0.5), stages=stages)
+        pipe.sync()
+        q.put((rank, y0, y1, bool(torch.equal(band, ref[y0:y1]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["needed", "allgather"])
+def test_config5_banded_two_ranks_one_gpu(exchange):
+    """BASELINE config 5 sharded over ranks: AHD(3) per band from host rows with halo, exchange of the rows the warp
+    needs (gloo + host staging here; RCCL send/recv on a multi-GPU node), row-limited warp == whole-frame result."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_banded_gpu_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=240) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    assert res == [(0, 0, 200, True), (1, 200, 400, True)]
