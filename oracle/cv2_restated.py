@@ -13,7 +13,7 @@ routine rgb2lab_px and are called through oracle.rgb2lab.
 
 Call sites (relative to /root/reference): ahd.py:58,62,64,77-80,120-121,133-134,151;
 edge_assisted_gaussian.py:86-87,141,143,156,170,184; fast_resize.py:28-29,39;
-dng_warp_corr/chan_distortion_corr.py:94-97.
+dng_warp_corr/chan_distortion_corr.py:94-97; corr_ca/ca_removal.py:96-127 (remap INTER_LINEAR).
 """
 from __future__ import annotations
 
@@ -141,11 +141,28 @@ def _lanczos4_tab() -> np.ndarray:
 
 
 def remap(src, mapx, mapy, interpolation):
-    assert interpolation == INTER_LANCZOS4 and src.dtype == np.float32 and src.ndim == 2
+    assert interpolation in (INTER_LANCZOS4, INTER_LINEAR) and src.dtype == np.float32 and src.ndim == 2
     H, W = src.shape
-    tab = _lanczos4_tab()
     sx = np.rint(mapx.astype(np.float32) * _F(32)).astype(np.int64)
     sy = np.rint(mapy.astype(np.float32) * _F(32)).astype(np.int64)
+    if interpolation == INTER_LINEAR:
+        # corr_ca/ca_removal.py:96-127.  Coordinates quantised to 1/32 px like every cv2.remap mode; the 2x2 weights are
+        # float products of the 1-D taps (1 - f, f); BORDER_CONSTANT 0; sum in source order, left to right.
+        ix, iy = sx >> 5, sy >> 5
+        fx = (sx & 31).astype(np.float32) * _F(1.0 / 32.0)
+        fy = (sy & 31).astype(np.float32) * _F(1.0 / 32.0)
+        wx = (_F(1) - fx, fx)
+        wy = (_F(1) - fy, fy)
+        p = np.pad(src, ((1, 1), (1, 1)), mode="constant")
+        out = None
+        for r in range(2):
+            yy = np.clip(iy + r + 1, 0, H + 1)
+            for c in range(2):
+                xx = np.clip(ix + c + 1, 0, W + 1)
+                t = p[yy, xx] * (wy[r] * wx[c])
+                out = t if out is None else out + t
+        return out
+    tab = _lanczos4_tab()
     ix, iy = (sx >> 5) - 3, (sy >> 5) - 3
     wx, wy = tab[sx & 31], tab[sy & 31]           # (H,W,8)
     p = np.pad(src, ((8, 8), (8, 8)), mode="constant")

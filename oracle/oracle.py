@@ -395,6 +395,25 @@ def remap_lanczos4(src, mapx, mapy) -> np.ndarray:
     return out
 
 
+def remap_linear(src, mapx, mapy) -> np.ndarray:
+    src, mapx, mapy = _f32(src), _f32(mapx), _f32(mapy)
+    out = np.empty_like(src)
+    _chk(lib().orc_remap_linear(_p(src), src.shape[0], src.shape[1], _p(mapx), _p(mapy), _p(out)), "remap_linear")
+    return out
+
+
+def remove_ca(bayer, quad_g_at_r=None, quad_r_at_g=None, wb_r: float = 1.0, quad_g_at_b=None, quad_b_at_g=None, wb_b: float = 1.0) -> np.ndarray:
+    """corr_ca/ca_removal.py:48-131 with the lens models' quadrant coordinate fields (h,w,2) given; returns the new mosaic."""
+    out = _f32(bayer).copy()
+    H, W = out.shape
+    qs = [None if q is None else _f32(q) for q in (quad_g_at_r, quad_r_at_g, quad_g_at_b, quad_b_at_g)]
+    for q in qs:
+        assert q is None or q.shape == (H // 2, W // 2, 2)
+    ptr = [None if q is None else _p(q) for q in qs]
+    _chk(lib().orc_remove_ca(_p(out), H, W, ptr[0], ptr[1], ctypes.c_float(wb_r), ptr[2], ptr[3], ctypes.c_float(wb_b)), "remove_ca")
+    return out
+
+
 def warp_rectilinear(image, coeffs, centre, scale: float = 1.0) -> np.ndarray:
     img = _f32(image).copy()
     H, W, _ = img.shape

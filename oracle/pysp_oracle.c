@@ -986,6 +986,109 @@ int orc_warp_rectilinear(float *image, int H, int W, const double *coeffs, int p
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Restated cv2.remap(INTER_LINEAR), BORDER_CONSTANT 0, float32 (corr_ca/ca_removal.py:96-127).  UNPINNED.
+ * Coordinates are quantised to 1/32 px (round half even) like every cv2.remap mode; the four weights are the
+ * float products of the 1-D taps (1 - f, f); the sum runs in source order, left to right. */
+static inline float remap_linear_px(const float *src, int H, int W, float mx, float my) {
+    int sx = (int)lrintf(mx * 32.0f), sy = (int)lrintf(my * 32.0f);
+    int ix = sx >> 5, iy = sy >> 5;
+    float fx = (float)(sx & 31) * (1.0f / 32.0f), fy = (float)(sy & 31) * (1.0f / 32.0f);
+    float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
+    float sum = 0.0f;
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++) {
+            int yy = iy + r, xx = ix + c;
+            float v = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? src[(size_t)yy * W + xx] : 0.0f;
+            float t = v * (wy[r] * wx[c]);
+            sum = (r == 0 && c == 0) ? t : sum + t;
+        }
+    return sum;
+}
+int orc_remap_linear(const float *src, int H, int W, const float *mapx, const float *mapy, float *dst) {
+#pragma omp parallel for
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            size_t o = (size_t)y * W + x;
+            dst[o] = remap_linear_px(src, H, W, mapx[o], mapy[o]);
+        }
+    return ORC_OK;
+}
+
+/* corr_ca/model/generic.py:56-101,131-163: the coordinate field of a lens model is built for the top-left quadrant
+ * (h,w,2) = (dy, dx) relative to the image centre and mirrored with sign flips into the other three; ca_removal.py:96-99
+ * then adds (size-1)/2 and clips to [0, size-1].  quad: (h,w,2) float32. */
+static inline void ca_map(const float *quad, int H, int W, int y, int x, float *mx, float *my) {
+    int h = H / 2, w = W / 2;
+    int qy = y < h ? y : H - 1 - y, qx = x < w ? x : W - 1 - x;
+    float dy = quad[((size_t)qy * w + qx) * 2], dx = quad[((size_t)qy * w + qx) * 2 + 1];
+    if (y >= h) dy = -dy;
+    if (x >= w) dx = -dx;
+    float cx = (float)(((double)W - 1.0) / 2.0), cy = (float)(((double)H - 1.0) / 2.0);
+    float ax = dx + cx, ay = dy + cy, xmax = (float)(W - 1), ymax = (float)(H - 1);
+    *mx = ax < 0.0f ? 0.0f : (ax > xmax ? xmax : ax);
+    *my = ay < 0.0f ? 0.0f : (ay > ymax ? ymax : ay);
+}
+static void ca_remap_full(const float *src, int H, int W, const float *quad, float *dst) {
+#pragma omp parallel for
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float mx, my;
+            ca_map(quad, H, W, y, x, &mx, &my);
+            dst[(size_t)y * W + x] = remap_linear_px(src, H, W, mx, my);
+        }
+}
+/* corr_ca/ca_removal.py:48-131 remove_ca_from_raw for one channel: site (oy,ox) = (0,0) red / (1,1) blue, pos 0 / 3.
+ * chan is the (h,w) plane, overwritten with the corrected samples. */
+static int ca_channel(float *chan, const float *g_full, int H, int W, const float *quad_g_at_c, const float *quad_c_at_g, float wb,
+                      int pos) {
+    int h = H / 2, w = W / 2, oy = pos == 0 ? 0 : 1, ox = oy;
+    size_t n = (size_t)h * w, N = (size_t)H * W;
+    planes_t gq = {0, 0, NULL, NULL, NULL, NULL};
+    float *g_at = falloc(N), *blur = falloc(N), *hf = falloc(N), *up = falloc(N), *sub = falloc(n);
+    int rc = ORC_ENOMEM;
+    if (planes_alloc(&gq, h, w) || !g_at || !blur || !hf || !up || !sub) goto done;
+    ca_remap_full(g_full, H, W, quad_g_at_c, g_at);                                   /* :96-100 / :114-118 */
+    for (size_t i = 0; i < n; i++) sub[i] = chan[i] * wb;                             /* :102 / :120 */
+    orc_gaussian_blur3(g_at, H, W, blur);                                             /* eag.py:170 / :184 */
+    for (size_t i = 0; i < N; i++) hf[i] = g_at[i] - blur[i];
+    orc_bayer_to_rgbg_f32(g_at, H, W, gq.r, gq.g1, gq.b, gq.g2);
+    if ((rc = resample_channel(sub, pos == 0 ? gq.r : gq.b, hf, h, w, pos, up))) goto done;
+#pragma omp parallel for
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            float mx, my;
+            ca_map(quad_c_at_g, H, W, 2 * i + oy, 2 * j + ox, &mx, &my);               /* :104-108 / :122-126 */
+            chan[(size_t)i * w + j] = remap_linear_px(up, H, W, mx, my) / wb;        /* :110 / :128 */
+        }
+    rc = ORC_OK;
+done:
+    planes_free(&gq);
+    free(g_at); free(blur); free(hf); free(up); free(sub);
+    return rc;
+}
+/* bayer (H,W) float32 in place.  A NULL pair of quadrant fields leaves that channel untouched (lens model None). */
+int orc_remove_ca(float *bayer, int H, int W, const float *quad_g_at_r, const float *quad_r_at_g, float wb_r, const float *quad_g_at_b,
+                  const float *quad_b_at_g, float wb_b) {
+    if (H < 2 || W < 2 || (H & 1) || (W & 1)) return ORC_EBADARG;
+    if ((!quad_g_at_r) != (!quad_r_at_g) || (!quad_g_at_b) != (!quad_b_at_g)) return ORC_EBADARG;
+    if (!quad_g_at_r && !quad_g_at_b) return ORC_OK;                                  /* :74-75 */
+    int h = H / 2, w = W / 2, rc = ORC_ENOMEM;
+    planes_t p = {0, 0, NULL, NULL, NULL, NULL};
+    float *g_full = falloc((size_t)H * W);
+    if (planes_alloc(&p, h, w) || !g_full) goto done;
+    orc_bayer_to_rgbg_f32(bayer, H, W, p.r, p.g1, p.b, p.g2);                         /* :84 */
+    if ((rc = orc_resample_g_full(p.g1, p.g2, h, w, g_full))) goto done;             /* :85 */
+    if (quad_g_at_r && (rc = ca_channel(p.r, g_full, H, W, quad_g_at_r, quad_r_at_g, wb_r, 0))) goto done;
+    if (quad_g_at_b && (rc = ca_channel(p.b, g_full, H, W, quad_g_at_b, quad_b_at_g, wb_b, 3))) goto done;
+    orc_rgbg_to_bayer_f32(p.r, p.g1, p.b, p.g2, h, w, bayer);                         /* :130 */
+    rc = ORC_OK;
+done:
+    planes_free(&p);
+    free(g_full);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * raw_bad_pixel_corr.py:30-65 find_erroneous_pixels_threshold: per CFA plane, np.pad(..., mode="reflect")
  * (= REFLECT_101), eight neighbours, hot where more than min_neighbour_count of them are below
  * (chan - min_delta) (float32 subtraction, python-float weak scalar).  masks: four (h,w) uint8 planes r,g1,b,g2. */

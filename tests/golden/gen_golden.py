@@ -317,6 +317,43 @@ def main():
              image=img, blob=np.frombuffer(blob, dtype=np.uint8), prior=prior, warped=warped_prior)
         save("g10_warp_apply", {"ref": "dng_warp_corr/chan_distortion_corr.py:43-121", "cv2_restated": True, "native": "oracle/_ref"},
              image=img, blob=np.frombuffer(blob, dtype=np.uint8), coeffs=np.array(coeffs), centre=np.array([0.5, 0.5]), warped=warped)
+
+        # ---- G12 chromatic-aberration removal: the apply half of corr_ca (model fitting is not on the path)
+        # tile_roi_finder.py:5 imports `pipeline.border_control.linework.line`, a module that is not part of the
+        # reference tree; it is only used by the fitting code, so an empty stand-in lets ca_removal import.
+        for name in ("pipeline", "pipeline.border_control", "pipeline.border_control.linework", "pipeline.border_control.linework.line"):
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules["pipeline.border_control.linework.line"].Line2DXeY = sys.modules["pipeline.border_control.linework.line"].Line2DYeX = object
+        from pySP.corr_ca.ca_removal import remove_ca_from_raw
+        from pySP.corr_ca.model.poly3 import Poly3CorrectionModel
+        from pySP.corr_ca.model.poly5 import Poly5CorrectionModel
+        from pySP.corr_ca.model.ptlens import PtLensCorrectionModel
+        models = {
+            "poly5_pyfloat": (lambda: Poly5CorrectionModel(0.03, -0.008), [0.03, -0.008]),
+            "poly5_f64": (lambda: Poly5CorrectionModel(np.float64(-0.025), np.float64(0.012)), [-0.025, 0.012]),
+            "poly3_pyfloat": (lambda: Poly3CorrectionModel(0.02), [0.02]),
+            "ptlens_f64": (lambda: PtLensCorrectionModel(np.float64(0.01), np.float64(-0.02), np.float64(0.025)), [0.01, -0.02, 0.025]),
+        }
+        H, W = 40, 56
+        probe = np.zeros((H, W), np.float32)
+        arrays, meta_models = {}, {}
+        for key, (make, coefs) in models.items():
+            m = make()
+            arrays[key + "_undist"] = m.get_undistorted_coordinates(probe)[:H // 2, :W // 2].astype(np.float32)
+            arrays[key + "_dist"] = m.get_distorted_coordinates(probe)[:H // 2, :W // 2].astype(np.float32)
+            full = m.get_distorted_coordinates(probe)
+            arrays[key + "_dist_full"] = full
+            meta_models[key] = coefs
+        bay = scene(H, W, 77)
+        cases = {"both": ("poly5_pyfloat", "poly5_f64"), "r_only": ("ptlens_f64", None), "b_only": (None, "poly3_pyfloat")}
+        for cname, (kr, kb) in cases.items():
+            raw = RawRggbBayerData(bay.copy(), FakeWb(MULT, XYZ2CAM[0]), 10.0, 1.0)
+            remove_ca_from_raw(raw, models[kr][0]() if kr else None, models[kb][0]() if kb else None)
+            arrays["out_" + cname] = raw.sensor_scaled
+        save("g12_ca_removal", {"ref": "corr_ca/ca_removal.py:48-131, corr_ca/model/{generic,poly3,poly5,ptlens}.py", "cv2_restated": True, "io_stubs": True,
+                                "solver_stub": "pipeline.border_control.linework.line (absent from the reference tree, fitting only)",
+                                "models": meta_models, "cases": {k: list(v) for k, v in cases.items()}, "mult": [float(v) for v in MULT]},
+             bayer=bay, **arrays)
     finally:
         sys.path.remove(farm)
         shutil.rmtree(farm, ignore_errors=True)

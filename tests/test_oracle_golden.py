@@ -164,3 +164,41 @@ def test_g10_warp_prior(orc):
         tab = orc.warp_table(*k, W, H, cx, cy, 1.0, seed=np.ascontiguousarray(d["prior"][:, :, c, :]))
         out[..., c] = orc.remap_lanczos4(np.ascontiguousarray(img[..., c]), np.clip(tab[..., 0], 0, W - 1), np.clip(tab[..., 1], 0, H - 1))
     assert np.array_equal(out, d["warped"])
+
+
+def test_g12_ca_removal(orc):
+    """corr_ca/ca_removal.py:48-131 through the reference's own remove_ca_from_raw and lens models."""
+    d, meta = load_golden("g12_ca_removal")
+    assert meta["cv2_restated"]
+    H, W = d["bayer"].shape
+    mult = np.array(meta["mult"], np.float32)
+    wb = (np.float32(1.0) / mult).astype(np.float32)
+    for key in meta["models"]:
+        # the full field is the quadrant mirrored with sign flips (generic.py:84-99)
+        q, full = d[key + "_dist"], d[key + "_dist_full"]
+        assert np.array_equal(full[:H // 2, :W // 2], q)
+        tr = q[:, ::-1].copy(); tr[..., 1] = -tr[..., 1]
+        assert np.array_equal(full[:H // 2, W // 2:], tr)
+        bot = full[:H // 2][::-1].copy(); bot[..., 0] = -bot[..., 0]
+        assert np.array_equal(full[H // 2:], bot)
+    for cname, (kr, kb) in meta["cases"].items():
+        out = orc.remove_ca(d["bayer"],
+                            d[kr + "_undist"] if kr else None, d[kr + "_dist"] if kr else None, float(wb[0]),
+                            d[kb + "_undist"] if kb else None, d[kb + "_dist"] if kb else None, float(wb[2]))
+        assert np.array_equal(out, d["out_" + cname]), cname
+        assert not np.array_equal(out, d["bayer"])
+        # green samples are never touched
+        assert np.array_equal(out[0::2, 1::2], d["bayer"][0::2, 1::2]) and np.array_equal(out[1::2, 0::2], d["bayer"][1::2, 0::2])
+    assert np.array_equal(orc.remove_ca(d["bayer"]), d["bayer"])
+
+
+def test_remap_linear_vs_numpy_restatement(orc):
+    from oracle import cv2_restated as cv2r
+    rng = np.random.default_rng(5)
+    src = rng.random((23, 31), dtype=np.float32)
+    mx = (rng.random((23, 31), dtype=np.float32) * 36 - 3).astype(np.float32)
+    my = (rng.random((23, 31), dtype=np.float32) * 28 - 3).astype(np.float32)
+    mx[0, :4] = [0.0, 30.0, 29.984375, 30.015625]; my[0, :4] = [22.0, 0.0, 21.5, 22.0]
+    assert np.array_equal(orc.remap_linear(src, mx, my), cv2r.remap(src, mx, my, cv2r.INTER_LINEAR))
+    ident = orc.remap_linear(src, *np.meshgrid(np.arange(31, dtype=np.float32), np.arange(23, dtype=np.float32)))
+    assert np.array_equal(ident, src)
