@@ -88,6 +88,12 @@ int pysp_resample_channel_f32(pysp_ctx *ctx, const float *sub, const float *g_su
  * raw_bad_pixel_corr.py:30-65 find_erroneous_pixels_threshold: four (H/2,W/2) uint8 masks (1 = hot) for the
  * r,g1,b,g2 planes. */
 int pysp_find_hot_pixels_f32(pysp_ctx *ctx, const float *bayer, int H, int W, float min_delta, int min_neighbour_count, uint8_t *mask_r, uint8_t *mask_g1, uint8_t *mask_b, uint8_t *mask_g2);
+/* corr_ca/ca_removal.py:48-131 remove_ca_from_raw, the apply half (lens-model fitting is host work): bayer (H,W) float32
+ * is corrected in place.  Each quad_* is the top-left quadrant (H/2,W/2,2) = (dy,dx) of a lens model's coordinate field
+ * (corr_ca/model/generic.py:56-101 get_distorted_coordinates for *_r_at_g / *_b_at_g, :113-163 get_undistorted_coordinates
+ * for *_g_at_r / *_g_at_b); the library mirrors it into the other quadrants.  A NULL pair skips that channel (model None);
+ * wb_r / wb_b are cam_wb.get_reciprocal_multipliers()[0] / [2]. */
+int pysp_remove_ca_f32(pysp_ctx *ctx, float *bayer, int H, int W, const float *quad_g_at_r, const float *quad_r_at_g, float wb_r, const float *quad_g_at_b, const float *quad_b_at_g, float wb_b);
 /* raw_correction.py:25-62 flat_frame_correction on mosaics; mean[4] = np.mean of the flat's r,g1,b,g2 planes
  * (:44, computed by the caller with NumPy so that the float32 pairwise-summation order is NumPy's). */
 int pysp_flat_field_f32(pysp_ctx *ctx, const float *bayer, const float *flat, int H, int W, const float mean[4], int clamp_high, float *out);

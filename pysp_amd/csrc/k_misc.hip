@@ -435,3 +435,78 @@ int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, in
     hipLaunchKernelGGL(k_warp_remap, grid, dim3(256), 0, st, p);
     return CHECK_LAUNCH();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Lateral chromatic-aberration removal, the apply half of corr_ca/ca_removal.py:48-131.
+// A lens model's coordinate field exists for the top-left quadrant only ((h,w,2) = (dy,dx) from the image centre,
+// corr_ca/model/generic.py:56-101); the other quadrants are mirror images with the sign of one component flipped,
+// so the kernels mirror on the fly instead of reading a full (H,W,2) field.  ca_removal.py:96-99 then adds
+// (size-1)/2 and clips to [0, size-1]; the sample is the restated cv2.remap(INTER_LINEAR): 1/32 px quantisation,
+// weights = float products of (1-f, f), BORDER_CONSTANT 0, summed in source order (oracle remap_linear_px).
+namespace {
+struct CaGeom { int H, W, h, w; float cx, cy, xmax, ymax; };
+DEVI void ca_map(const float* __restrict__ quad, const CaGeom& g, int y, int x, float& mx, float& my) {
+    int qy = y < g.h ? y : g.H - 1 - y, qx = x < g.w ? x : g.W - 1 - x;
+    float2 d = *reinterpret_cast<const float2*>(quad + ((size_t)qy * g.w + qx) * 2);
+    float dy = y >= g.h ? -d.x : d.x, dx = x >= g.w ? -d.y : d.y;
+    float ax = dx + g.cx, ay = dy + g.cy;
+    mx = ax < 0.0f ? 0.0f : (ax > g.xmax ? g.xmax : ax);
+    my = ay < 0.0f ? 0.0f : (ay > g.ymax ? g.ymax : ay);
+}
+DEVI float remap_linear_px(const float* __restrict__ src, int H, int W, float mx, float my) {
+    int sx = (int)rintf(mx * 32.0f), sy = (int)rintf(my * 32.0f);
+    int ix = sx >> 5, iy = sy >> 5;
+    float fx = (float)(sx & 31) * (1.0f / 32.0f), fy = (float)(sy & 31) * (1.0f / 32.0f);
+    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    bool y0 = (unsigned)iy < (unsigned)H, y1 = (unsigned)(iy + 1) < (unsigned)H, x0 = (unsigned)ix < (unsigned)W, x1 = (unsigned)(ix + 1) < (unsigned)W;
+    const float* p = src + (size_t)(y0 ? iy : 0) * W;
+    const float* q = src + (size_t)(y1 ? iy + 1 : 0) * W;
+    float v00 = (y0 && x0) ? p[ix] : 0.0f, v01 = (y0 && x1) ? p[ix + 1] : 0.0f;
+    float v10 = (y1 && x0) ? q[ix] : 0.0f, v11 = (y1 && x1) ? q[ix + 1] : 0.0f;
+    return ((v00 * (wy0 * wx0) + v01 * (wy0 * fx)) + v10 * (fy * wx0)) + v11 * (fy * fx);
+}
+CaGeom ca_geom(int H, int W) {
+    CaGeom g;
+    g.H = H; g.W = W; g.h = H / 2; g.w = W / 2;
+    g.cx = (float)(((double)W - 1.0) / 2.0); g.cy = (float)(((double)H - 1.0) / 2.0);
+    g.xmax = (float)(W - 1); g.ymax = (float)(H - 1);
+    return g;
+}
+}  // namespace
+// ca_removal.py:96-100 / :114-118: the whole plane resampled at a model's coordinates
+__global__ void __launch_bounds__(256) k_ca_remap_full(const float* __restrict__ src, CaGeom g, const float* __restrict__ quad, float* __restrict__ dst) {
+    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= g.H) return;
+    float mx, my;
+    ca_map(quad, g, y, x, mx, my);
+    dst[(size_t)y * g.W + x] = remap_linear_px(src, g.H, g.W, mx, my);
+}
+// ca_removal.py:104-110 / :122-128: only the samples at the channel's own photosites survive (bayer_to_rgbg(...)[0] or [2]),
+// divided by the white-balance multiplier that was applied before the resampling
+__global__ void __launch_bounds__(256) k_ca_remap_sites(const float* __restrict__ src, CaGeom g, const float* __restrict__ quad, int oy, int ox, float wb,
+                                                        float* __restrict__ chan) {
+    int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= g.w || i >= g.h) return;
+    float mx, my;
+    ca_map(quad, g, 2 * i + oy, 2 * j + ox, mx, my);
+    chan[(size_t)i * g.w + j] = remap_linear_px(src, g.H, g.W, mx, my) / wb;
+}
+__global__ void __launch_bounds__(256) k_scale_plane(const float* __restrict__ in, size_t n, float s, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i] * s;
+}
+int launch_ca_remap_full(hipStream_t st, const float* src, int H, int W, const float* d_quad, float* dst) {
+    dim3 grid((W + 63) / 64, (H + 3) / 4);
+    hipLaunchKernelGGL(k_ca_remap_full, grid, dim3(256), 0, st, src, ca_geom(H, W), d_quad, dst);
+    return CHECK_LAUNCH();
+}
+int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* chan) {
+    dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4);
+    hipLaunchKernelGGL(k_ca_remap_sites, grid, dim3(256), 0, st, src, ca_geom(H, W), d_quad, oy, ox, wb, chan);
+    return CHECK_LAUNCH();
+}
+int launch_scale_plane(hipStream_t st, const float* in, size_t n, float s, float* out) {
+    hipLaunchKernelGGL(k_scale_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, s, out);
+    return CHECK_LAUNCH();
+}

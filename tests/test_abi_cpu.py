@@ -140,6 +140,11 @@ def test_reference_import_paths_exist():
         "pysp_amd.raw_correction": ["flat_frame_correction"],
         "pysp_amd.dng_warp_corr": ["apply_opcode_3_warp", "stack_warp_prior"],
         "pysp_amd.dng_warp_corr.dng_warp_rectilinear_coords": ["compute_remapping_table", "compute_offset_remapping_table"],
+        "pysp_amd.corr_ca.ca_removal": ["remove_ca_from_raw"],
+        "pysp_amd.corr_ca.model.generic": ["CaCorrectionModel", "ReversibleModelMixin", "NewtonRaphsonModel", "get_empty_coord_field", "get_empty_radius_field"],
+        "pysp_amd.corr_ca.model.poly3": ["Poly3CorrectionModel"],
+        "pysp_amd.corr_ca.model.poly5": ["Poly5CorrectionModel"],
+        "pysp_amd.corr_ca.model.ptlens": ["PtLensCorrectionModel"],
     }.items():
         m = importlib.import_module(mod)
         for n in names:

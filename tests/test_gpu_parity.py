@@ -728,3 +728,38 @@ def test_config5_banded_two_ranks_one_gpu(exchange):
                 p.kill()
     assert all(p.exitcode == 0 for p in procs)
     assert res == [(0, 0, 200, True), (1, 200, 400, True)]
+
+
+def test_ca_removal_golden_and_oracle(orc, wbobj):
+    """corr_ca/ca_removal.py:48-131: fixture from the reference's remove_ca_from_raw, then larger frames vs the oracle."""
+    from pysp_amd.corr_ca import remove_ca_from_raw
+    from pysp_amd.corr_ca.model.poly3 import Poly3CorrectionModel
+    from pysp_amd.corr_ca.model.poly5 import Poly5CorrectionModel
+    from pysp_amd.corr_ca.model.ptlens import PtLensCorrectionModel
+    from pysp_amd.synth import rggb_frame
+    d, meta = load_golden("g12_ca_removal")
+    mk = {"poly5_pyfloat": lambda c: Poly5CorrectionModel(*c), "poly5_f64": lambda c: Poly5CorrectionModel(*[np.float64(v) for v in c]),
+          "poly3_pyfloat": lambda c: Poly3CorrectionModel(*c), "ptlens_f64": lambda c: PtLensCorrectionModel(*[np.float64(v) for v in c])}
+    for cname, (kr, kb) in meta["cases"].items():
+        raw = _raw(d["bayer"].copy(), wbobj)
+        remove_ca_from_raw(raw, mk[kr](meta["models"][kr]) if kr else None, mk[kb](meta["models"][kb]) if kb else None)
+        assert raw.sensor_scaled.dtype == np.float32 and np.array_equal(raw.sensor_scaled, d["out_" + cname]), cname
+    wb = wbobj.get_reciprocal_multipliers()
+    for (H, W, seed) in [(2, 2, 1), (6, 4, 2), (130, 66, 3), (600, 900, 4)]:
+        bay = rggb_frame(H, W, seed) if H > 8 else np.random.default_rng(seed).random((H, W), dtype=np.float32)
+        mr, mb = Poly5CorrectionModel(0.05, -0.01), PtLensCorrectionModel(np.float64(-0.02), np.float64(0.03), np.float64(-0.04))
+        raw = _raw(bay.copy(), wbobj)
+        remove_ca_from_raw(raw, mr, mb)
+        ref = orc.remove_ca(bay, mr.get_undistorted_quadrant(bay), mr.get_distorted_quadrant(bay), float(wb[0]),
+                            mb.get_undistorted_quadrant(bay), mb.get_distorted_quadrant(bay), float(wb[2]))
+        assert np.array_equal(raw.sensor_scaled, ref), (H, W)
+        assert np.array_equal(raw.sensor_scaled[0::2, 1::2], bay[0::2, 1::2])            # green untouched
+        if H > 100:
+            assert np.mean(raw.sensor_scaled[0::2, 0::2] != bay[0::2, 0::2]) > 0.5
+    # a channel without a model keeps its samples; an identity model still goes through the resampling filters
+    bay = rggb_frame(64, 96, 9)
+    raw = _raw(bay.copy(), wbobj)
+    ident = Poly5CorrectionModel()
+    remove_ca_from_raw(raw, ident, None)
+    assert np.array_equal(raw.sensor_scaled[1::2, 1::2], bay[1::2, 1::2])
+    assert np.array_equal(raw.sensor_scaled, orc.remove_ca(bay, ident.get_undistorted_quadrant(bay), ident.get_distorted_quadrant(bay), float(wb[0])))
