@@ -94,6 +94,8 @@ int pysp_find_hot_pixels_f32(pysp_ctx *ctx, const float *bayer, int H, int W, fl
  * for *_g_at_r / *_g_at_b); the library mirrors it into the other quadrants.  A NULL pair skips that channel (model None);
  * wb_r / wb_b are cam_wb.get_reciprocal_multipliers()[0] / [2]. */
 int pysp_remove_ca_f32(pysp_ctx *ctx, float *bayer, int H, int W, const float *quad_g_at_r, const float *quad_r_at_g, float wb_r, const float *quad_g_at_b, const float *quad_b_at_g, float wb_b);
+/* Same with the mosaic and the four quadrant fields resident on the device (a lens's fields are uploaded once per batch). */
+int pysp_remove_ca_dev(pysp_ctx *ctx, float *d_bayer, int H, int W, const float *d_quad_g_at_r, const float *d_quad_r_at_g, float wb_r, const float *d_quad_g_at_b, const float *d_quad_b_at_g, float wb_b);
 /* raw_correction.py:25-62 flat_frame_correction on mosaics; mean[4] = np.mean of the flat's r,g1,b,g2 planes
  * (:44, computed by the caller with NumPy so that the float32 pairwise-summation order is NumPy's). */
 int pysp_flat_field_f32(pysp_ctx *ctx, const float *bayer, const float *flat, int H, int W, const float mean[4], int clamp_high, float *out);

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "pysp_remap_lanczos4_f32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp]),
     "pysp_warp_rectilinear_dev": (_int, [_vp, _vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt]),
     "pysp_remove_ca_f32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _flt, _vp, _vp, _flt]),
+    "pysp_remove_ca_dev": (_int, [_vp, _vp, _int, _int, _vp, _vp, _flt, _vp, _vp, _flt]),
     "pysp_warp_rectilinear_rows_dev": (_int, [_vp, _vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt, _int, _int]),
     "pysp_warp_source_rows": (_int, [_vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt, _int, _int, _intp, _intp]),
 }

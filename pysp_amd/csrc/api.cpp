@@ -607,47 +607,67 @@ int pysp_warp_rectilinear_prior_f32(pysp_ctx* ctx, float* image, int H, int W, c
     return pysp_ctx_sync(ctx);
 }
 // ---- corr_ca/ca_removal.py:48-131 remove_ca_from_raw, apply half --------------------------------------------------------
-static int ca_channel(pysp_ctx* ctx, float* d_chan, const float* d_gfull, int H, int W, const float* quad_g_at_c, const float* quad_c_at_g, float wb, int pos,
-                      float* d_q0, float* d_q1, float* d_gat, float* d_hf, float* d_up, float* d_sub, float* d_gsite, float* d_t[3]) {
+struct CaScratch { float *gfull, *gat, *hf, *up, *sub, *gsite, *t[3], *p[4]; };
+static int ca_channel(pysp_ctx* ctx, float* d_chan, int H, int W, const float* d_quad_g_at_c, const float* d_quad_c_at_g, float wb, int pos, const CaScratch& s) {
     const int h = H / 2, w = W / 2;
     const size_t n = (size_t)h * w;
-    TRY(h2d(ctx, d_q0, quad_g_at_c, n * 8)); TRY(h2d(ctx, d_q1, quad_c_at_g, n * 8));
     ctx->tl.begin(ctx->stream, "k_ca_remap_full");
-    LAUNCH_TRY(launch_ca_remap_full(ctx->stream, d_gfull, H, W, d_q0, d_gat));                       // green as the channel sees it
+    LAUNCH_TRY(launch_ca_remap_full(ctx->stream, s.gfull, H, W, d_quad_g_at_c, s.gat));                // green as the channel sees it
     ctx->tl.end(ctx->stream);
-    LAUNCH_TRY(launch_scale_plane(ctx->stream, d_chan, n, wb, d_sub));
-    LAUNCH_TRY(launch_highpass(ctx->stream, d_gat, H, W, d_hf));                                      // eag.py:170 / :184
-    if (pos == 0) LAUNCH_TRY(launch_demux_f32(ctx->stream, d_gat, H, W, d_gsite, d_t[0], d_t[1], d_t[2]));
-    else LAUNCH_TRY(launch_demux_f32(ctx->stream, d_gat, H, W, d_t[0], d_t[1], d_gsite, d_t[2]));
-    LAUNCH_TRY(launch_resample_channel(ctx->stream, d_sub, d_gsite, d_hf, h, w, pos, d_up));          // full-resolution channel
+    LAUNCH_TRY(launch_scale_plane(ctx->stream, d_chan, n, wb, s.sub));
+    LAUNCH_TRY(launch_highpass(ctx->stream, s.gat, H, W, s.hf));                                       // eag.py:170 / :184
+    if (pos == 0) LAUNCH_TRY(launch_demux_f32(ctx->stream, s.gat, H, W, s.gsite, s.t[0], s.t[1], s.t[2]));
+    else LAUNCH_TRY(launch_demux_f32(ctx->stream, s.gat, H, W, s.t[0], s.t[1], s.gsite, s.t[2]));
+    LAUNCH_TRY(launch_resample_channel(ctx->stream, s.sub, s.gsite, s.hf, h, w, pos, s.up));           // full-resolution channel
     ctx->tl.begin(ctx->stream, "k_ca_remap_sites");
-    LAUNCH_TRY(launch_ca_remap_sites(ctx->stream, d_up, H, W, d_q1, pos == 0 ? 0 : 1, pos == 0 ? 0 : 1, wb, d_chan));
+    LAUNCH_TRY(launch_ca_remap_sites(ctx->stream, s.up, H, W, d_quad_c_at_g, pos == 0 ? 0 : 1, pos == 0 ? 0 : 1, wb, d_chan));
     ctx->tl.end(ctx->stream);
     return PYSP_OK;
+}
+static int ca_check(const void* bayer, int H, int W, const float* q0, const float* q1, float wb_r, const float* q2, const float* q3, float wb_b) {
+    if (!bayer || !even_dims(H, W)) return fail(PYSP_EBADARG, "remove_ca: need a mosaic with even H,W >= 2 (got %dx%d)", H, W);
+    if ((!q0) != (!q1) || (!q2) != (!q3)) return fail(PYSP_EBADARG, "remove_ca: a channel needs both of its coordinate fields");
+    if ((q0 && !(wb_r != 0.0f)) || (q2 && !(wb_b != 0.0f))) return fail(PYSP_EBADARG, "remove_ca: zero white-balance multiplier");
+    return PYSP_OK;
+}
+// d_bayer and the four quadrant fields are device pointers; the mosaic is corrected in place
+static int ca_core(pysp_ctx* ctx, float* d_bayer, int H, int W, const float* d_q0, const float* d_q1, float wb_r, const float* d_q2, const float* d_q3, float wb_b) {
+    const int h = H / 2, w = W / 2;
+    const size_t n = (size_t)h * w, N = (size_t)H * W;
+    CaScratch s;
+    for (int i = 0; i < 4; i++) RESERVE(ctx, S_P0 + i, n * 4, s.p[i]);
+    RESERVE(ctx, S_OUT, N * 4, s.gfull); RESERVE(ctx, S_TMP0, N * 4, s.gat); RESERVE(ctx, S_TMP1, N * 4, s.hf); RESERVE(ctx, S_AUX, N * 4, s.up);
+    RESERVE(ctx, S_FR0 + 4, n * 4, s.sub); RESERVE(ctx, S_FR0 + 5, n * 4, s.gsite);
+    for (int i = 0; i < 3; i++) RESERVE(ctx, S_FR0 + 6 + i, n * 4, s.t[i]);
+    ctx->tic();
+    LAUNCH_TRY(launch_demux_f32(ctx->stream, d_bayer, H, W, s.p[0], s.p[1], s.p[2], s.p[3]));         // r, g1, b, g2
+    LAUNCH_TRY(launch_resample_g(ctx->stream, s.p[1], s.p[3], h, w, 1, s.gfull));                     // :85
+    if (d_q0) TRY(ca_channel(ctx, s.p[0], H, W, d_q0, d_q1, wb_r, 0, s));
+    if (d_q2) TRY(ca_channel(ctx, s.p[2], H, W, d_q2, d_q3, wb_b, 3, s));
+    LAUNCH_TRY(launch_remux_f32(ctx->stream, s.p[0], s.p[1], s.p[2], s.p[3], h, w, d_bayer));        // :130
+    ctx->toc();
+    return PYSP_OK;
+}
+int pysp_remove_ca_dev(pysp_ctx* ctx, float* d_bayer, int H, int W, const float* d_quad_g_at_r, const float* d_quad_r_at_g, float wb_r,
+                       const float* d_quad_g_at_b, const float* d_quad_b_at_g, float wb_b) {
+    CTX_ENTER(ctx);
+    TRY(ca_check(d_bayer, H, W, d_quad_g_at_r, d_quad_r_at_g, wb_r, d_quad_g_at_b, d_quad_b_at_g, wb_b));
+    if (!d_quad_g_at_r && !d_quad_g_at_b) return PYSP_OK;                                             // ca_removal.py:74-75
+    return ca_core(ctx, d_bayer, H, W, d_quad_g_at_r, d_quad_r_at_g, wb_r, d_quad_g_at_b, d_quad_b_at_g, wb_b);
 }
 int pysp_remove_ca_f32(pysp_ctx* ctx, float* bayer, int H, int W, const float* quad_g_at_r, const float* quad_r_at_g, float wb_r,
                        const float* quad_g_at_b, const float* quad_b_at_g, float wb_b) {
     CTX_ENTER(ctx);
-    if (!bayer || !even_dims(H, W)) return fail(PYSP_EBADARG, "remove_ca: need a mosaic with even H,W >= 2 (got %dx%d)", H, W);
-    if ((!quad_g_at_r) != (!quad_r_at_g) || (!quad_g_at_b) != (!quad_b_at_g)) return fail(PYSP_EBADARG, "remove_ca: a channel needs both of its coordinate fields");
-    if (!quad_g_at_r && !quad_g_at_b) return PYSP_OK;                                                 // ca_removal.py:74-75
-    if ((quad_g_at_r && !(wb_r != 0.0f)) || (quad_g_at_b && !(wb_b != 0.0f))) return fail(PYSP_EBADARG, "remove_ca: zero white-balance multiplier");
-    const int h = H / 2, w = W / 2;
-    const size_t n = (size_t)h * w, N = (size_t)H * W;
-    float *d_bayer, *d_p[4], *d_gfull, *d_gat, *d_hf, *d_up, *d_q0, *d_q1, *d_sub, *d_gsite, *d_t[3];
+    TRY(ca_check(bayer, H, W, quad_g_at_r, quad_r_at_g, wb_r, quad_g_at_b, quad_b_at_g, wb_b));
+    if (!quad_g_at_r && !quad_g_at_b) return PYSP_OK;
+    const size_t n = (size_t)(H / 2) * (W / 2), N = (size_t)H * W;
+    const float* hq[4] = {quad_g_at_r, quad_r_at_g, quad_g_at_b, quad_b_at_g};
+    float *d_bayer, *d_q[4] = {nullptr, nullptr, nullptr, nullptr};
     RESERVE(ctx, S_IN, N * 4, d_bayer);
-    for (int i = 0; i < 4; i++) RESERVE(ctx, S_P0 + i, n * 4, d_p[i]);
-    RESERVE(ctx, S_OUT, N * 4, d_gfull); RESERVE(ctx, S_TMP0, N * 4, d_gat); RESERVE(ctx, S_TMP1, N * 4, d_hf); RESERVE(ctx, S_AUX, N * 4, d_up);
-    RESERVE(ctx, S_FR0, n * 8, d_q0); RESERVE(ctx, S_FR0 + 1, n * 8, d_q1); RESERVE(ctx, S_FR0 + 2, n * 4, d_sub); RESERVE(ctx, S_FR0 + 3, n * 4, d_gsite);
-    for (int i = 0; i < 3; i++) RESERVE(ctx, S_FR0 + 4 + i, n * 4, d_t[i]);
     TRY(h2d(ctx, d_bayer, bayer, N * 4));
-    ctx->tic();
-    LAUNCH_TRY(launch_demux_f32(ctx->stream, d_bayer, H, W, d_p[0], d_p[1], d_p[2], d_p[3]));       // r, g1, b, g2
-    LAUNCH_TRY(launch_resample_g(ctx->stream, d_p[1], d_p[3], h, w, 1, d_gfull));                     // :85
-    if (quad_g_at_r) TRY(ca_channel(ctx, d_p[0], d_gfull, H, W, quad_g_at_r, quad_r_at_g, wb_r, 0, d_q0, d_q1, d_gat, d_hf, d_up, d_sub, d_gsite, d_t));
-    if (quad_g_at_b) TRY(ca_channel(ctx, d_p[2], d_gfull, H, W, quad_g_at_b, quad_b_at_g, wb_b, 3, d_q0, d_q1, d_gat, d_hf, d_up, d_sub, d_gsite, d_t));
-    LAUNCH_TRY(launch_remux_f32(ctx->stream, d_p[0], d_p[1], d_p[2], d_p[3], h, w, d_bayer));        // :130
-    ctx->toc();
+    for (int i = 0; i < 4; i++)
+        if (hq[i]) { RESERVE(ctx, S_FR0 + i, n * 8, d_q[i]); TRY(h2d(ctx, d_q[i], hq[i], n * 8)); }
+    TRY(ca_core(ctx, d_bayer, H, W, d_q[0], d_q[1], wb_r, d_q[2], d_q[3], wb_b));
     TRY(d2h(ctx, bayer, d_bayer, N * 4));
     return pysp_ctx_sync(ctx);
 }

@@ -121,6 +121,26 @@ class DevicePipeline:
                                                     cf.size // 6, float(centre[0]), float(centre[1]), float(scale)))
         return out
 
+    def lens_fields(self, lens_model, shape):
+        """Upload the two coordinate quadrants of a corr_ca lens model for frames of `shape` once; pass the result to
+        `remove_ca` for every frame taken with that lens."""
+        probe = np.zeros(shape, np.float32)
+        inv = np.ascontiguousarray(lens_model.get_undistorted_quadrant(probe), dtype=np.float32)
+        fwd = np.ascontiguousarray(lens_model.get_distorted_quadrant(probe), dtype=np.float32)
+        return self.torch.from_numpy(inv).to(self.device), self.torch.from_numpy(fwd).to(self.device)
+
+    def remove_ca(self, bayer, wb, fields_r=None, fields_b=None):
+        """corr_ca/ca_removal.py:48-131 in place on a device-resident float32 mosaic; fields_* from `lens_fields`."""
+        self._check_bayer(bayer)
+        H, W = int(bayer.shape[0]), int(bayer.shape[1])
+        for f in (fields_r, fields_b):
+            if f is not None and (len(f) != 2 or any(t.shape != (H // 2, W // 2, 2) or t.dtype != self.torch.float32 or not t.is_contiguous() for t in f)):
+                raise ValueError("lens fields must be two contiguous float32 (H/2, W/2, 2) tensors for this frame size")
+        q = [_dp(fields_r[0]) if fields_r else None, _dp(fields_r[1]) if fields_r else None, _dp(fields_b[0]) if fields_b else None, _dp(fields_b[1]) if fields_b else None]
+        self._enter()
+        _lib.check(self.L.pysp_remove_ca_dev(self.ctx.handle, _dp(bayer), H, W, q[0], q[1], float(np.float32(wb[0])), q[2], q[3], float(np.float32(wb[2]))))
+        return bayer
+
     def warp_rows(self, rgb, coeffs, centre: Tuple[float, float], row0: int, row1: int, out, scale: float = 1.0):
         """Output rows [row0, row1) of `warp` only; `rgb` and `out` are whole-frame (H,W,3) device buffers of which
         only the rows `warp_source_rows` names need to hold valid data (one band of a frame sharded over GPUs)."""

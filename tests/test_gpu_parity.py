@@ -763,3 +763,32 @@ def test_ca_removal_golden_and_oracle(orc, wbobj):
     remove_ca_from_raw(raw, ident, None)
     assert np.array_equal(raw.sensor_scaled[1::2, 1::2], bay[1::2, 1::2])
     assert np.array_equal(raw.sensor_scaled, orc.remove_ca(bay, ident.get_undistorted_quadrant(bay), ident.get_distorted_quadrant(bay), float(wb[0])))
+
+
+def test_ca_removal_device_resident_batch(orc, wbobj):
+    """pysp_remove_ca_dev: lens fields uploaded once, several frames corrected in place on the device, then demosaiced."""
+    import torch
+    from pysp_amd.corr_ca.model.poly5 import Poly5CorrectionModel
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    pipe = DevicePipeline(0)
+    wb, M = _wbM(orc)
+    H, W = 256, 384
+    mr, mb = Poly5CorrectionModel(0.03, -0.008), Poly5CorrectionModel(np.float64(-0.025), np.float64(0.012))
+    fr, fb = pipe.lens_fields(mr, (H, W)), pipe.lens_fields(mb, (H, W))
+    for seed in (11, 12, 13):
+        bay = rggb_frame(H, W, seed)
+        d = torch.from_numpy(bay).cuda()
+        pipe.remove_ca(d, wb, fr, fb)
+        rgb = pipe.demosaic(d, wb, M, stages=1)
+        pipe.sync()
+        ref = orc.remove_ca(bay, fr[0].cpu().numpy(), fr[1].cpu().numpy(), float(wb[0]), fb[0].cpu().numpy(), fb[1].cpu().numpy(), float(wb[2]))
+        assert np.array_equal(d.cpu().numpy(), ref), seed
+        assert np.array_equal(rgb.cpu().numpy(), orc.demosaic_ahd(ref, wb, M, False, 1))
+    only_b = torch.from_numpy(rggb_frame(H, W, 14)).cuda()
+    keep = only_b.clone()
+    pipe.remove_ca(only_b, wb, None, fb)
+    pipe.sync()
+    assert torch.equal(only_b[0::2, 0::2], keep[0::2, 0::2]) and not torch.equal(only_b[1::2, 1::2], keep[1::2, 1::2])
+    with pytest.raises(ValueError):
+        pipe.remove_ca(only_b, wb, (fr[0][:10], fr[1][:10]), None)
