@@ -1,0 +1,40 @@
+"""End-to-end (PCIe-inclusive) timing of the drop-in NumPy API at 24 MP on the GPU box: python tools/dropin_time.py"""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pysp_amd import _lib
+from pysp_amd.colorize import lin_srgb_to_srgb
+from pysp_amd.colorize.transform import final_matrix
+from pysp_amd.const import QualityDemosaic
+from pysp_amd.image import RawRggbBayerData
+from pysp_amd.synth import default_wb, rggb_frame
+
+H, W = 4000, 6000
+bay = rggb_frame(H, W, 1000)
+wbobj = default_wb()
+for it in range(3):
+    t0 = time.perf_counter()
+    raw = RawRggbBayerData(bay, wbobj, 10.0, 1.0)
+    lin = raw.demosaic(QualityDemosaic.Best).to_lin_srgb()
+    t1 = time.perf_counter()
+    srgb = lin_srgb_to_srgb(lin)
+    t2 = time.perf_counter()
+    print("README recipe: demosaic+to_lin_srgb %.1f ms, lin_srgb_to_srgb %.1f ms, total %.1f ms = %.2f GMP/s" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, H * W / 1e9 / (t2 - t0)))
+L = _lib.lib(); ctx = _lib.default_context()
+wb = _lib.wb3(wbobj.get_reciprocal_multipliers()); M = _lib.mat9(final_matrix(wbobj.get_matrix()))
+out = np.empty((H, W, 3), np.float32)
+for it in range(4):
+    t0 = time.perf_counter()
+    _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, wb, M, 2, 0, 1, 0, _lib.ptr(out)))
+    t1 = time.perf_counter()
+    print("one fused call (host buffers): %.1f ms = %.2f GMP/s, kernels %.2f ms" % ((t1 - t0) * 1e3, H * W / 1e9 / (t1 - t0), ctx.last_kernel_ms()))
+assert np.array_equal(out, srgb)
+# raw copy rates
+d = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+pin = torch.empty(H * W * 3, dtype=torch.float32).pin_memory()
+pag = torch.from_numpy(out.reshape(-1))
+for name, h in (("pageable", pag), ("pinned", pin)):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); d.copy_(h, non_blocking=True); torch.cuda.synchronize(); t1 = time.perf_counter()
+    h.copy_(d, non_blocking=True); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("%s: H2D %.1f GB/s, D2H %.1f GB/s" % (name, h.numel() * 4 / 1e9 / (t1 - t0), h.numel() * 4 / 1e9 / (t2 - t1)))
