@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpysp_hip.so")
+LIB_PATH = os.environ.get("PYSP_HIP_LIB") or os.path.join(_HERE, "csrc", "libpysp_hip.so")   # override: kernel A/B experiments
 
 PYSP_OK, PYSP_EBADARG, PYSP_ENOTIMPL, PYSP_EHIP, PYSP_ENOMEM = 0, -1, -2, -3, -4
 QUALITY_DRAFT, QUALITY_FAST, QUALITY_BEST = 0, 1, 2

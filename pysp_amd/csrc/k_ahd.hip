@@ -84,6 +84,8 @@ DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool a
 // DIR 1: from the up/down neighbours (map_v).  The centre and the two epsilon neighbours always count:
 // x - c <= max(|c - x|, .) and the chroma distance of a neighbour is one of the two maximised squares
 // (d*d == (-d)*(-d) bit for bit), so only the other six window cells are tested.
+// (Measured and dropped: evaluating the six pixel pairs inside the quad once for both of their pixels saves 36 of
+// ~240 operations per direction but costs 12 VGPRs -- one wave of occupancy or spills -- and runs 3-25 % slower.)
 template <int DIR>
 DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
 #pragma unroll
@@ -259,7 +261,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             for (int k = 0; k < 4; k++) {
                 homog_lab(lt, rr[k], gg[k], bb[k], p.wb, M, p.hdr, labq[k][0], labq[k][1], labq[k][2]);
                 rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
+#ifndef AHD_NO_SB
                 __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
+#endif
             }
         }
         if (dir == 1) __syncthreads();   // votes of direction 0 are done reading the Lab buffer
