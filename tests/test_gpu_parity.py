@@ -792,3 +792,40 @@ def test_ca_removal_device_resident_batch(orc, wbobj):
     assert torch.equal(only_b[0::2, 0::2], keep[0::2, 0::2]) and not torch.equal(only_b[1::2, 1::2], keep[1::2, 1::2])
     with pytest.raises(ValueError):
         pipe.remove_ca(only_b, wb, (fr[0][:10], fr[1][:10]), None)
+
+
+def test_contexts_are_reentrant_across_threads(orc, wbobj):
+    """SURVEY 8b threading: entry points are re-entrant per pysp_ctx (own stream + workspace); ctypes releases the GIL."""
+    import threading
+    from pysp_amd import _lib
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    H, W = 192, 256
+    frames = [rggb_frame(H, W, 50 + i) for i in range(4)]
+    refs = [orc.pipeline_srgb(f, wb, M, 2, False, 1, False) for f in frames]
+    outs = [[None] * 6 for _ in frames]
+    errors = []
+
+    def work(i):
+        try:
+            ctx = _lib.Context(0)
+            wb3, m9 = _lib.wb3(wb), _lib.mat9(M)
+            for rep in range(6):
+                out = np.empty((H, W, 3), np.float32)
+                _lib.check(_lib.lib().pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(frames[i]), H, W, wb3, m9, 2, 0, 1, 0, _lib.ptr(out)))
+                outs[i][rep] = out
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(frames))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for i in range(len(frames)):
+        for rep in range(6):
+            assert np.array_equal(outs[i][rep], refs[i]), (i, rep)
+    # the error string is per thread: a failure elsewhere does not leak into this thread's message
+    rc = _lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(frames[0]), 3, 5, _lib.wb3(wb), _lib.mat9(M), 2, 0, 1, _lib.ptr(outs[0][0]))
+    assert rc != 0 and b"even" in _lib.lib().pysp_last_error()
