@@ -6,7 +6,10 @@
 // Coefficients are computed in float64 with libm and cast to float32; tests/test_abi_cpu.py checks that the
 // tables equal the CPU oracle's (an independent build of the same definition) bit for bit.
 #pragma once
-constexpr int LAB_DEC_NB = 6, LAB_DEC_LOEXP = -5, LAB_DEC_N = 5 * (1 << LAB_DEC_NB) + 1;   // v in [2^-5, 1]
+#ifndef PYSP_LAB_DEC_NB
+#define PYSP_LAB_DEC_NB 6                      // experiments only: the oracle's tables are built for 6
+#endif
+constexpr int LAB_DEC_NB = PYSP_LAB_DEC_NB, LAB_DEC_LOEXP = -5, LAB_DEC_N = 5 * (1 << LAB_DEC_NB) + 1;   // v in [2^-5, 1]
 constexpr int LAB_CB_NB = 5, LAB_CB_LOEXP = -7, LAB_CB_N = 8 * (1 << LAB_CB_NB) + 1;       // t in [2^-7, 2)
 // Host side: fills dec[LAB_DEC_N*4] and cb[LAB_CB_N*4] (segment order).
 void host_lab_tables(float* dec, float* cb);
@@ -14,5 +17,5 @@ void host_lab_tables(float* dec, float* cb);
 // bit field [23-NB, 23-NB+log2(SLOTS)) of the argument.  decode: 122<<6 = 7808 = 128 (mod 512), so segments 0..320
 // occupy slots 128..448; cube root: 120<<5 = 3840 = 0 (mod 256), segments 0..255 occupy slots 0..255 (segment 256
 // starts at t = 2 and is never addressed: X, Y, Z <= 1.0000001).  Unused slots are zero.
-constexpr int LAB_DEC_SLOTS = 512, LAB_CB_SLOTS = 256, LAB_SLOTS = LAB_DEC_SLOTS + LAB_CB_SLOTS;   // 768 x 16 B = 12 KB
+constexpr int LAB_DEC_SLOTS = 8 << LAB_DEC_NB, LAB_CB_SLOTS = 256, LAB_SLOTS = LAB_DEC_SLOTS + LAB_CB_SLOTS;   // 768 x 16 B = 12 KB
 void host_lab_slots(float* slots /* LAB_SLOTS*4 */);
