@@ -85,7 +85,7 @@ DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool a
 // x - c <= max(|c - x|, .) and the chroma distance of a neighbour is one of the two maximised squares
 // (d*d == (-d)*(-d) bit for bit), so only the other six window cells are tested.
 // (Measured and dropped: evaluating the six pixel pairs inside the quad once for both of their pixels saves 36 of
-// ~240 operations per direction but costs 12 VGPRs -- one wave of occupancy or spills -- and runs 3-25 % slower.)
+// ~240 operations per direction but costs 12-16 VGPRs: 3-25 % slower at 165 VGPRs, +-0.5 % at 137 (SLP threshold 20).)
 template <int DIR>
 DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
 #pragma unroll
