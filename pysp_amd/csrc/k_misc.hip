@@ -232,10 +232,14 @@ struct RemapParams {
     float scale;
 };
 namespace {
-constexpr int WBX = 64, WBY = 8;            // output block of one workgroup (two rows per thread)
-constexpr int WTW = 96, WTH = 24;           // largest per-channel source tile staged in LDS: 3 x 9 KB
+#ifndef WARP_RPT
+#define WARP_RPT 4                           // measured at 100 MP: 2 rows 2.28 ms, 3: 2.24, 4: 2.13, 5: 2.22, 6: 2.18, 8: 2.77
+#endif
+constexpr int WRPT = WARP_RPT;               // output rows per thread
+constexpr int WBX = 64, WBY = 4 * WRPT;     // output block of one workgroup
+constexpr int WTW = 96, WTH = WBY + 16;     // largest per-channel source tile staged in LDS: 3 x 12 KB at 16 rows
 }
-// One workgroup = 64x8 output pixels.  Each channel has its own smooth warp, so the 8x8 Lanczos footprints of
+// One workgroup = 64x16 output pixels (four rows per thread).  Each channel has its own smooth warp, so the 8x8 Lanczos footprints of
 // a block cover a small source rectangle per channel, bounded by the block's corner pixels (+2 cells): it is
 // staged in LDS once per channel (zero outside the image = BORDER_CONSTANT 0) and the 64 taps per pixel and
 // channel are conflict-free LDS reads.  A pixel whose footprint is not inside the staged rectangle (extreme
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     const int tid = threadIdx.x;
     stab[tid] = p.tab[tid];
     const int by0 = p.row0 + blockIdx.y * WBY;
-    const int x = blockIdx.x * WBX + (tid & 63), y0 = by0 + (tid >> 6) * 2;
+    const int x = blockIdx.x * WBX + (tid & 63), y0 = by0 + (tid >> 6) * WRPT;
     const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
     auto cell = [&](float mx, float my, int& fx, int& fy) {
         mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);       // np.clip, chan_distortion_corr.py:95-96
@@ -262,9 +266,9 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
         cell(mx, my, fx, fy);
         corner[c][k][0] = fx >> 5; corner[c][k][1] = fy >> 5;
     }
-    int sx[2][3], sy[2][3];
+    int sx[WRPT][3], sy[WRPT][3];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < WRPT; j++) {
         WarpRad wr = warp_rad((float)x, (float)(y0 + j), p.g);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -275,6 +279,8 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     }
     __syncthreads();
     int tx0[3], ty0[3], tw[3], th[3];
+    constexpr int NLD = (WTW * WTH + 255) / 256;     // tile cells per thread and channel
+    float stage[3][NLD];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         int lox = min(min(corner[c][0][0], corner[c][1][0]), min(corner[c][2][0], corner[c][3][0]));
@@ -283,19 +289,26 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
         int hiy = max(max(corner[c][0][1], corner[c][1][1]), max(corner[c][2][1], corner[c][3][1]));
         tx0[c] = lox - 3 - 2; ty0[c] = loy - 3 - 2;            // 2 cells of margin on every side
         tw[c] = min(hix + 4 + 2 - tx0[c] + 1, WTW); th[c] = min(hiy + 4 + 2 - ty0[c] + 1, WTH);
-        const int n = tw[c] * th[c];
-        for (int idx = tid; idx < n; idx += 256) {
-            int ry = idx / tw[c], rx = idx - ry * tw[c];
+        // all loads of the three tiles are issued before the first LDS store (cells are addressed on the fixed WTW grid:
+        // constant divisions, and every cell of the buffer gets a value -- zero outside the image or the rectangle)
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            int idx = tid + k * 256;
+            int ry = idx / WTW, rx = idx - ry * WTW;
             int gx = tx0[c] + rx, gy = ty0[c] + ry;
-            float v = 0.0f;
-            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) v = p.in[((size_t)gy * p.W + gx) * 3 + c];
-            tile[c][ry * WTW + rx] = v;
+            bool ok = ry < th[c] && rx < tw[c] && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            stage[c][k] = ok ? p.in[((size_t)gy * p.W + gx) * 3 + c] : 0.0f;
         }
     }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < NLD; k++)
+            if ((k + 1) * 256 <= WTW * WTH || tid + k * 256 < WTW * WTH) tile[c][tid + k * 256] = stage[c][k];
     __syncthreads();
     if (x >= p.W) return;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < WRPT; j++) {
         const int y = y0 + j;
         if (y >= p.row1) break;
         float res[3];
@@ -307,18 +320,26 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
             float sum = 0.0f;
             const int lx = ix - tx0[c], ly = iy - ty0[c];
             if (lx >= 0 && ly >= 0 && lx + 8 <= tw[c] && ly + 8 <= th[c]) {
-                const float* t0 = &tile[c][ly * WTW + lx];
-                for (int r = 0; r < 8; r++) {
+                const float* trow = &tile[c][ly * WTW + lx];
+                float wxr[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) wxr[t] = wx[t];
+#ifndef WARP_UNROLL_ROWS
+#pragma unroll 1   // one row per trip: the eight taps are immediate offsets from one row base (unrolled, each tap gets its own address add)
+#endif
+                for (int r = 0; r < 8; r++, trow += WTW) {
+                    const float wyr = wy[r];
                     float acc = 0.0f;
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
-                        float v = t0[r * WTW + t] * (wy[r] * wx[t]);
+                        float v = trow[t] * (wyr * wxr[t]);
                         acc = t == 0 ? v : acc + v;
                     }
                     sum = sum + acc;
                 }
             } else {
-                for (int r = 0; r < 8; r++) {
+#pragma unroll 1
+                for (int r = 0; r < 8; r++) {   // rare (extreme distortion only): kept rolled, it would otherwise double the kernel's code size
                     int yy = iy + r;
                     bool yin = (unsigned)yy < (unsigned)p.H;
                     const float* row = p.in + ((size_t)(yin ? yy : 0) * p.W) * 3 + c;

@@ -8,7 +8,9 @@ tmp=$(mktemp -d)
 cp "$root"/pysp_amd/csrc/*.hip "$root"/pysp_amd/csrc/*.h "$root"/pysp_amd/csrc/*.inc "$root"/pysp_amd/csrc/*.cpp "$root"/pysp_amd/csrc/Makefile "$tmp"/
 mkdir -p "$tmp/../../include" 2>/dev/null || true
 sed -i "s#\.\./\.\./include/pysp_hip.h#$root/include/pysp_hip.h#g" "$tmp"/Makefile "$tmp"/api.cpp
-make -C "$tmp" EXTRA="$*" -j4 >/dev/null
+extra=(); vars=()
+for a in "$@"; do if [[ "$a" =~ ^[A-Z]+= ]]; then vars+=("$a"); else extra+=("$a"); fi; done   # VAR=value goes to make, the rest to the compiler
+make -C "$tmp" EXTRA="${extra[*]}" "${vars[@]}" -j4 >/dev/null
 mkdir -p "$root/tools/scratch"
 cp "$tmp/libpysp_hip.so" "$root/tools/scratch/$name.so"
 rm -rf "$tmp"
