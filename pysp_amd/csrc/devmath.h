@@ -9,6 +9,24 @@
 
 #define DEVI static __device__ __forceinline__
 
+// ---- XCD-aware tile order --------------------------------------------------------------------
+// MI355X hands consecutive workgroups to its 8 XCDs round-robin, and each XCD has its own L2: with the plain
+// blockIdx -> tile map, neighbouring tiles (which share their halo rows and columns) always sit on different L2s.
+// This map gives XCD k the k-th contiguous eighth of the row-major tile sequence instead, so a tile's neighbours --
+// left/right, and one tile row up/down (a tile row of a 24 MP frame is ~1 MB, the L2 4 MB) -- are served by its own L2.
+#ifndef PYSP_XCD_SWIZZLE
+#define PYSP_XCD_SWIZZLE 1
+#endif
+DEVI void xcd_tile(int& bx, int& by) {
+    bx = blockIdx.x; by = blockIdx.y;
+#if PYSP_XCD_SWIZZLE
+    const unsigned gx = gridDim.x, n = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned xcd = lin & 7u, q = n >> 3, r = n & 7u;
+    const unsigned t = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);   // XCD k owns q (+1 if k < r) consecutive tiles
+    by = (int)(t / gx); bx = (int)(t - (unsigned)by * gx);
+#endif
+}
+
 // ---- border index rules: cv2 BORDER_REFLECT / REFLECT_101 / REPLICATE ----------
 DEVI int b_sym(int p, int n) {
     if (n == 1) return 0;

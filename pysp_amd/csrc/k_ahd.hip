@@ -143,7 +143,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
-    const int tq0x = blockIdx.x * TQX, tq0y = blockIdx.y * TQY;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const double* M = p.ccm.m;
 
     // ---- P0: white-balanced mosaic planes, symmetric (edge-duplicating) reflect per plane (ahd.py:77-80).
@@ -417,7 +419,9 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
     __shared__ __attribute__((aligned(16))) float s_r1[B2Y][B2X], s_b1[B2Y][B2X];                     // r', b'      (halo 2)
     __shared__ __attribute__((aligned(16))) float s_d1[B2Y][B2X], s_d2[B2Y][B2X];                     // g-r', g-b'  (halo 2)
     const int tid = threadIdx.x, H = p.H, W = p.W;
-    const int tx0 = blockIdx.x * BTX, ty0 = blockIdx.y * BTY;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int tx0 = tbx * BTX, ty0 = tby * BTY;
 
     {   // all global loads of a thread are issued before its first LDS store (they are in flight together)
         constexpr int NL = (B4Y * B4X + NT_B - 1) / NT_B;

@@ -48,7 +48,9 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     __shared__ float gq[4][GY][GX];
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
-    const int tq0x = blockIdx.x * TQX, tq0y = blockIdx.y * TQY;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int tq0x = tbx * TQX, tq0y = tby * TQY;
 
     // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87).  One 8-byte load per quad
     // row; all loads of a thread are issued before the first LDS store so that they are in flight together.
