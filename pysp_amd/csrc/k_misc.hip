@@ -250,8 +250,10 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     __shared__ int corner[3][4][2];          // per channel: source cell (ix, iy) of the block's four corner pixels
     const int tid = threadIdx.x;
     stab[tid] = p.tab[tid];
-    const int by0 = p.row0 + blockIdx.y * WBY;
-    const int x = blockIdx.x * WBX + (tid & 63), y0 = by0 + (tid >> 6) * WRPT;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int by0 = p.row0 + tby * WBY;
+    const int x = tbx * WBX + (tid & 63), y0 = by0 + (tid >> 6) * WRPT;
     const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
     auto cell = [&](float mx, float my, int& fx, int& fy) {
         mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);       // np.clip, chan_distortion_corr.py:95-96
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     };
     if (tid < 12) {
         const int c = tid >> 2, k = tid & 3;
-        int cx = min(blockIdx.x * WBX + ((k & 1) ? WBX - 1 : 0), p.W - 1), cy = min(by0 + ((k & 2) ? WBY - 1 : 0), p.row1 - 1);
+        int cx = min(tbx * WBX + ((k & 1) ? WBX - 1 : 0), p.W - 1), cy = min(by0 + ((k & 2) ? WBY - 1 : 0), p.row1 - 1);
         float mx, my; int fx, fy;
         warp_px((float)cx, (float)cy, p.k[c], p.g, p.scale, mx, my);
         cell(mx, my, fx, fy);
