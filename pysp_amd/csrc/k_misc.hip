@@ -442,8 +442,9 @@ int launch_warp_src_rows(hipStream_t st, int H, int W, const double* coeffs, int
     RemapParams p;
     p.in = nullptr; p.out = nullptr; p.tab = nullptr;
     if (fill_remap_params(p, H, W, coeffs, planes, cxn, cyn, scale, row0, row1)) return -1;
-    const int init[2] = {0x7fffffff, -0x7fffffff - 1};
-    if (hipMemcpyAsync(d_rows, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    // (device-side fills: an async copy from this stack frame could outlive it)
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_rows), 0x7fffffff, 1, st) != hipSuccess ||
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_rows + 1), (int)0x80000000u, 1, st) != hipSuccess) return -1;
     dim3 grid((W + 255) / 256, row1 - row0);
     hipLaunchKernelGGL(k_warp_src_rows, grid, dim3(256), 0, st, p, d_rows);
     return CHECK_LAUNCH();
