@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert L.pysp_abi_version() == 1
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/pysp_hip.h compiles as C99 with warnings as errors, and a C client links and runs against the library."""
+    import subprocess
+    exe = str(tmp_path / "c_abi_check")
+    lib_dir = os.path.join(ROOT, "pysp_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", os.path.join(ROOT, "tests", "c_abi_check.c"), "-o", exe,
+                           "-L" + lib_dir, "-lpysp_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.device_count() > 0:

@@ -829,3 +829,17 @@ def test_contexts_are_reentrant_across_threads(orc, wbobj):
     # the error string is per thread: a failure elsewhere does not leak into this thread's message
     rc = _lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(frames[0]), 3, 5, _lib.wb3(wb), _lib.mat9(M), 2, 0, 1, _lib.ptr(outs[0][0]))
     assert rc != 0 and b"even" in _lib.lib().pysp_last_error()
+
+
+def test_c_client_runs_on_gpu(tmp_path):
+    """tests/c_abi_check.c (plain C99, no Python, no torch) against the library on the GPU: context, one demosaic, error codes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_check")
+    lib_dir = os.path.join(root, "pysp_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", os.path.join(root, "tests", "c_abi_check.c"), "-o", exe,
+                           "-L" + lib_dir, "-lpysp_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok (GPU"), out.stdout + out.stderr
+    assert "0.5 0.25 0.357143" in out.stdout          # Draft of a flat 0.25 mosaic times wb = (2, 1, 1/0.7)
