@@ -607,20 +607,16 @@ int pysp_warp_rectilinear_prior_f32(pysp_ctx* ctx, float* image, int H, int W, c
     return pysp_ctx_sync(ctx);
 }
 // ---- corr_ca/ca_removal.py:48-131 remove_ca_from_raw, apply half --------------------------------------------------------
-struct CaScratch { float *gfull, *gat, *hf, *up, *sub, *gsite, *t[3], *p[4]; };
-static int ca_channel(pysp_ctx* ctx, float* d_chan, int H, int W, const float* d_quad_g_at_c, const float* d_quad_c_at_g, float wb, int pos, const CaScratch& s) {
-    const int h = H / 2, w = W / 2;
-    const size_t n = (size_t)h * w;
+struct CaScratch { float *gfull, *gat, *up; };
+static int ca_channel(pysp_ctx* ctx, float* d_bayer, int H, int W, const float* d_quad_g_at_c, const float* d_quad_c_at_g, float wb, int pos, const CaScratch& s) {
     ctx->tl.begin(ctx->stream, "k_ca_remap_full");
-    LAUNCH_TRY(launch_ca_remap_full(ctx->stream, s.gfull, H, W, d_quad_g_at_c, s.gat));                // green as the channel sees it
+    LAUNCH_TRY(launch_ca_remap_full(ctx->stream, s.gfull, H, W, d_quad_g_at_c, s.gat));               // :96-100 green as the channel sees it
     ctx->tl.end(ctx->stream);
-    LAUNCH_TRY(launch_scale_plane(ctx->stream, d_chan, n, wb, s.sub));
-    LAUNCH_TRY(launch_highpass(ctx->stream, s.gat, H, W, s.hf));                                       // eag.py:170 / :184
-    if (pos == 0) LAUNCH_TRY(launch_demux_f32(ctx->stream, s.gat, H, W, s.gsite, s.t[0], s.t[1], s.t[2]));
-    else LAUNCH_TRY(launch_demux_f32(ctx->stream, s.gat, H, W, s.t[0], s.t[1], s.gsite, s.t[2]));
-    LAUNCH_TRY(launch_resample_channel(ctx->stream, s.sub, s.gsite, s.hf, h, w, pos, s.up));           // full-resolution channel
+    ctx->tl.begin(ctx->stream, "k_ca_upsample");
+    LAUNCH_TRY(launch_ca_upsample(ctx->stream, d_bayer, s.gat, H, W, pos, wb, s.up));                  // :102 full-resolution channel
+    ctx->tl.end(ctx->stream);
     ctx->tl.begin(ctx->stream, "k_ca_remap_sites");
-    LAUNCH_TRY(launch_ca_remap_sites(ctx->stream, s.up, H, W, d_quad_c_at_g, pos == 0 ? 0 : 1, pos == 0 ? 0 : 1, wb, d_chan));
+    LAUNCH_TRY(launch_ca_remap_sites(ctx->stream, s.up, H, W, d_quad_c_at_g, pos == 0 ? 0 : 1, pos == 0 ? 0 : 1, wb, d_bayer));   // :104-110, :130
     ctx->tl.end(ctx->stream);
     return PYSP_OK;
 }
@@ -630,21 +626,17 @@ static int ca_check(const void* bayer, int H, int W, const float* q0, const floa
     if ((q0 && !(wb_r != 0.0f)) || (q2 && !(wb_b != 0.0f))) return fail(PYSP_EBADARG, "remove_ca: zero white-balance multiplier");
     return PYSP_OK;
 }
-// d_bayer and the four quadrant fields are device pointers; the mosaic is corrected in place
+// d_bayer and the four quadrant fields are device pointers; the mosaic is corrected in place.  Seven launches: green
+// upsampling once, then per channel remap -> upsample -> remap at the channel's photosites, written back into the mosaic
+// (the channels touch disjoint CFA sites, and green is only read).
 static int ca_core(pysp_ctx* ctx, float* d_bayer, int H, int W, const float* d_q0, const float* d_q1, float wb_r, const float* d_q2, const float* d_q3, float wb_b) {
-    const int h = H / 2, w = W / 2;
-    const size_t n = (size_t)h * w, N = (size_t)H * W;
+    const size_t N = (size_t)H * W;
     CaScratch s;
-    for (int i = 0; i < 4; i++) RESERVE(ctx, S_P0 + i, n * 4, s.p[i]);
-    RESERVE(ctx, S_OUT, N * 4, s.gfull); RESERVE(ctx, S_TMP0, N * 4, s.gat); RESERVE(ctx, S_TMP1, N * 4, s.hf); RESERVE(ctx, S_AUX, N * 4, s.up);
-    RESERVE(ctx, S_FR0 + 4, n * 4, s.sub); RESERVE(ctx, S_FR0 + 5, n * 4, s.gsite);
-    for (int i = 0; i < 3; i++) RESERVE(ctx, S_FR0 + 6 + i, n * 4, s.t[i]);
+    RESERVE(ctx, S_OUT, N * 4, s.gfull); RESERVE(ctx, S_TMP0, N * 4, s.gat); RESERVE(ctx, S_TMP1, N * 4, s.up);
     ctx->tic();
-    LAUNCH_TRY(launch_demux_f32(ctx->stream, d_bayer, H, W, s.p[0], s.p[1], s.p[2], s.p[3]));         // r, g1, b, g2
-    LAUNCH_TRY(launch_resample_g(ctx->stream, s.p[1], s.p[3], h, w, 1, s.gfull));                     // :85
-    if (d_q0) TRY(ca_channel(ctx, s.p[0], H, W, d_q0, d_q1, wb_r, 0, s));
-    if (d_q2) TRY(ca_channel(ctx, s.p[2], H, W, d_q2, d_q3, wb_b, 3, s));
-    LAUNCH_TRY(launch_remux_f32(ctx->stream, s.p[0], s.p[1], s.p[2], s.p[3], h, w, d_bayer));        // :130
+    LAUNCH_TRY(launch_ca_green(ctx->stream, d_bayer, H, W, s.gfull));                                  // :84-85
+    if (d_q0) TRY(ca_channel(ctx, d_bayer, H, W, d_q0, d_q1, wb_r, 0, s));
+    if (d_q2) TRY(ca_channel(ctx, d_bayer, H, W, d_q2, d_q3, wb_b, 3, s));
     ctx->toc();
     return PYSP_OK;
 }

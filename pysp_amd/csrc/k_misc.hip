@@ -506,31 +506,23 @@ __global__ void __launch_bounds__(256) k_ca_remap_full(const float* __restrict__
     ca_map(quad, g, y, x, mx, my);
     dst[(size_t)y * g.W + x] = remap_linear_px(src, g.H, g.W, mx, my);
 }
-// ca_removal.py:104-110 / :122-128: only the samples at the channel's own photosites survive (bayer_to_rgbg(...)[0] or [2]),
-// divided by the white-balance multiplier that was applied before the resampling
+// ca_removal.py:104-110 / :122-130: only the samples at the channel's own photosites survive (bayer_to_rgbg(...)[0] or [2]), divided
+// by the white-balance multiplier that was applied before the resampling; they are written straight back into the mosaic
 __global__ void __launch_bounds__(256) k_ca_remap_sites(const float* __restrict__ src, CaGeom g, const float* __restrict__ quad, int oy, int ox, float wb,
-                                                        float* __restrict__ chan) {
+                                                        float* __restrict__ bayer) {
     int j = blockIdx.x * 64 + (threadIdx.x & 63), i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (j >= g.w || i >= g.h) return;
     float mx, my;
     ca_map(quad, g, 2 * i + oy, 2 * j + ox, mx, my);
-    chan[(size_t)i * g.w + j] = remap_linear_px(src, g.H, g.W, mx, my) / wb;
-}
-__global__ void __launch_bounds__(256) k_scale_plane(const float* __restrict__ in, size_t n, float s, float* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = in[i] * s;
+    bayer[(size_t)(2 * i + oy) * g.W + 2 * j + ox] = remap_linear_px(src, g.H, g.W, mx, my) / wb;
 }
 int launch_ca_remap_full(hipStream_t st, const float* src, int H, int W, const float* d_quad, float* dst) {
     dim3 grid((W + 63) / 64, (H + 3) / 4);
     hipLaunchKernelGGL(k_ca_remap_full, grid, dim3(256), 0, st, src, ca_geom(H, W), d_quad, dst);
     return CHECK_LAUNCH();
 }
-int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* chan) {
+int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* bayer) {
     dim3 grid((W / 2 + 63) / 64, (H / 2 + 3) / 4);
-    hipLaunchKernelGGL(k_ca_remap_sites, grid, dim3(256), 0, st, src, ca_geom(H, W), d_quad, oy, ox, wb, chan);
-    return CHECK_LAUNCH();
-}
-int launch_scale_plane(hipStream_t st, const float* in, size_t n, float s, float* out) {
-    hipLaunchKernelGGL(k_scale_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, s, out);
+    hipLaunchKernelGGL(k_ca_remap_sites, grid, dim3(256), 0, st, src, ca_geom(H, W), d_quad, oy, ox, wb, bayer);
     return CHECK_LAUNCH();
 }

@@ -55,9 +55,10 @@ int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3
                       float cxn, float cyn, float scale, const float* d_seed, float* d_table);
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
                       double cyn, float scale, const float* d_lanczos_tab, int row0, int row1);
+int launch_ca_green(hipStream_t st, const float* bayer, int H, int W, float* out);
+int launch_ca_upsample(hipStream_t st, const float* bayer, const float* g_at, int H, int W, int pos, float wb, float* out);
 int launch_ca_remap_full(hipStream_t st, const float* src, int H, int W, const float* d_quad, float* dst);
-int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* chan);
-int launch_scale_plane(hipStream_t st, const float* in, size_t n, float s, float* out);
+int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* bayer);
 int launch_warp_src_rows(hipStream_t st, int H, int W, const double* coeffs, int planes, double cxn, double cyn, float scale, int row0, int row1,
                          int* d_rows);
 int launch_remap_table(hipStream_t st, const float* src, int sstride, const float* mapx, const float* mapy, int mstride, const float* d_tab,
