@@ -607,13 +607,10 @@ int pysp_warp_rectilinear_prior_f32(pysp_ctx* ctx, float* image, int H, int W, c
     return pysp_ctx_sync(ctx);
 }
 // ---- corr_ca/ca_removal.py:48-131 remove_ca_from_raw, apply half --------------------------------------------------------
-struct CaScratch { float *gfull, *gat, *up; };
+struct CaScratch { float *gfull, *up; };
 static int ca_channel(pysp_ctx* ctx, float* d_bayer, int H, int W, const float* d_quad_g_at_c, const float* d_quad_c_at_g, float wb, int pos, const CaScratch& s) {
-    ctx->tl.begin(ctx->stream, "k_ca_remap_full");
-    LAUNCH_TRY(launch_ca_remap_full(ctx->stream, s.gfull, H, W, d_quad_g_at_c, s.gat));               // :96-100 green as the channel sees it
-    ctx->tl.end(ctx->stream);
-    ctx->tl.begin(ctx->stream, "k_ca_upsample");
-    LAUNCH_TRY(launch_ca_upsample(ctx->stream, d_bayer, s.gat, H, W, pos, wb, s.up));                  // :102 full-resolution channel
+    ctx->tl.begin(ctx->stream, "k_ca_upsample_fused");
+    LAUNCH_TRY(launch_ca_upsample_fused(ctx->stream, d_bayer, s.gfull, H, W, d_quad_g_at_c, pos, wb, s.up));   // :96-102 green on the channel's geometry -> full-resolution channel
     ctx->tl.end(ctx->stream);
     ctx->tl.begin(ctx->stream, "k_ca_remap_sites");
     LAUNCH_TRY(launch_ca_remap_sites(ctx->stream, s.up, H, W, d_quad_c_at_g, pos == 0 ? 0 : 1, pos == 0 ? 0 : 1, wb, d_bayer));   // :104-110, :130
@@ -626,13 +623,13 @@ static int ca_check(const void* bayer, int H, int W, const float* q0, const floa
     if ((q0 && !(wb_r != 0.0f)) || (q2 && !(wb_b != 0.0f))) return fail(PYSP_EBADARG, "remove_ca: zero white-balance multiplier");
     return PYSP_OK;
 }
-// d_bayer and the four quadrant fields are device pointers; the mosaic is corrected in place.  Seven launches: green
-// upsampling once, then per channel remap -> upsample -> remap at the channel's photosites, written back into the mosaic
+// d_bayer and the four quadrant fields are device pointers; the mosaic is corrected in place.  Five launches: green
+// upsampling once, then per channel remap + upsample (one kernel) -> remap at the channel's photosites, written back into the mosaic
 // (the channels touch disjoint CFA sites, and green is only read).
 static int ca_core(pysp_ctx* ctx, float* d_bayer, int H, int W, const float* d_q0, const float* d_q1, float wb_r, const float* d_q2, const float* d_q3, float wb_b) {
     const size_t N = (size_t)H * W;
     CaScratch s;
-    RESERVE(ctx, S_OUT, N * 4, s.gfull); RESERVE(ctx, S_TMP0, N * 4, s.gat); RESERVE(ctx, S_TMP1, N * 4, s.up);
+    RESERVE(ctx, S_OUT, N * 4, s.gfull); RESERVE(ctx, S_TMP1, N * 4, s.up);
     ctx->tic();
     LAUNCH_TRY(launch_ca_green(ctx->stream, d_bayer, H, W, s.gfull));                                  // :84-85
     if (d_q0) TRY(ca_channel(ctx, d_bayer, H, W, d_q0, d_q1, wb_r, 0, s));

@@ -307,45 +307,8 @@ __global__ void __launch_bounds__(256) k_ca_green(const float* __restrict__ baye
     *reinterpret_cast<float2*>(out + (size_t)(2 * i) * W + 2 * j) = make_float2(gr, g1c);
     *reinterpret_cast<float2*>(out + (size_t)(2 * i + 1) * W + 2 * j) = make_float2(g2c, gb);
 }
-// :102 / :120  resample_r(r * wb, g_at) / resample_b(b * wb, g_at) = eag.py:160-186 + :126-143 in one pass: the channel's samples
-// come from its CFA site of the mosaic (times wb), green at the photosite from the same site of g_at, the high-pass of g_at
-// from the 4x4 window around the quad.  o = 0 (red, TOP_LEFT) or 1 (blue, BOTTOM_RIGHT).
-template <int O>
-__global__ void __launch_bounds__(256) k_ca_upsample(const float* __restrict__ bayer, const float* __restrict__ g_at, int H, int W, float wb,
-                                                     float* __restrict__ out) {
-    const int h = H >> 1, w = W >> 1;
-    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (j >= w) return;
-    Win3 wg, wd;
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {                                          // filter2D on the quarter planes: REFLECT_101 of the plane
-            size_t o = (size_t)(2 * b_101(i - 1 + r, h) + O) * W + 2 * b_101(j - 1 + c, w) + O;
-            float g = g_at[o];
-            wg.v[r][c] = g;
-            wd.v[r][c] = bayer[o] * wb - g;                                    // channel_diff (eag.py:142)
-        }
-    float Wn[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) Wn[r][c] = g_at[(size_t)b_101(2 * i - 1 + r, H) * W + b_101(2 * j - 1 + c, W)];   // GaussianBlur: REFLECT_101 at full resolution
-    float hf[4], fg[4], fd[4];
-    highpass_quad(Wn, hf);
-    if (O == 0) { filt_base_tl(wg, fg); filt_base_tl(wd, fd); } else { filt_base_br(wg, fg); filt_base_br(wd, fd); }
-    *reinterpret_cast<float2*>(out + (size_t)(2 * i) * W + 2 * j) = make_float2(fd[0] + (fg[0] + hf[0]), fd[1] + (fg[1] + hf[1]));
-    *reinterpret_cast<float2*>(out + (size_t)(2 * i + 1) * W + 2 * j) = make_float2(fd[2] + (fg[2] + hf[2]), fd[3] + (fg[3] + hf[3]));
-}
 int launch_ca_green(hipStream_t st, const float* bayer, int H, int W, float* out) {
     hipLaunchKernelGGL(k_ca_green, dim3((W / 2 + 255) / 256, H / 2), dim3(256), 0, st, bayer, H, W, out);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-int launch_ca_upsample(hipStream_t st, const float* bayer, const float* g_at, int H, int W, int pos, float wb, float* out) {
-    if (pos != 0 && pos != 3) return -1;
-    dim3 grid((W / 2 + 255) / 256, H / 2);
-    if (pos == 0) hipLaunchKernelGGL(k_ca_upsample<0>, grid, dim3(256), 0, st, bayer, g_at, H, W, wb, out);
-    else hipLaunchKernelGGL(k_ca_upsample<1>, grid, dim3(256), 0, st, bayer, g_at, H, W, wb, out);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

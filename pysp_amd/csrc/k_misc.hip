@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "devmath.h"
+#include "demosaic_common.h"
 #include "kernels.h"
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -3)
@@ -498,14 +499,6 @@ CaGeom ca_geom(int H, int W) {
     return g;
 }
 }  // namespace
-// ca_removal.py:96-100 / :114-118: the whole plane resampled at a model's coordinates
-__global__ void __launch_bounds__(256) k_ca_remap_full(const float* __restrict__ src, CaGeom g, const float* __restrict__ quad, float* __restrict__ dst) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= g.W || y >= g.H) return;
-    float mx, my;
-    ca_map(quad, g, y, x, mx, my);
-    dst[(size_t)y * g.W + x] = remap_linear_px(src, g.H, g.W, mx, my);
-}
 // ca_removal.py:104-110 / :122-130: only the samples at the channel's own photosites survive (bayer_to_rgbg(...)[0] or [2]), divided
 // by the white-balance multiplier that was applied before the resampling; they are written straight back into the mosaic
 __global__ void __launch_bounds__(256) k_ca_remap_sites(const float* __restrict__ src, CaGeom g, const float* __restrict__ quad, int oy, int ox, float wb,
@@ -516,9 +509,126 @@ __global__ void __launch_bounds__(256) k_ca_remap_sites(const float* __restrict_
     ca_map(quad, g, 2 * i + oy, 2 * j + ox, mx, my);
     bayer[(size_t)(2 * i + oy) * g.W + 2 * j + ox] = remap_linear_px(src, g.H, g.W, mx, my) / wb;
 }
-int launch_ca_remap_full(hipStream_t st, const float* src, int H, int W, const float* d_quad, float* dst) {
-    dim3 grid((W + 63) / 64, (H + 3) / 4);
-    hipLaunchKernelGGL(k_ca_remap_full, grid, dim3(256), 0, st, src, ca_geom(H, W), d_quad, dst);
+// ca_removal.py:96-102 / :114-120 in one kernel: green is pulled onto the channel's geometry (the bilinear remap of g_full at the
+// inverse model's coordinates) straight into an LDS tile, and resample_r / resample_b (eag.py:160-186 -> :126-143) runs on that tile:
+// the remapped green never goes to memory.  One workgroup = 32x8 CFA quads (64x16 px), one thread per quad; the tile carries a
+// 2 px ring (1 quad for the 3x3 quarter-plane filters, 1 px for the 3x3 blur).  Quads on the image border need two different
+// reflections of that ring (REFLECT_101 of the quarter plane for filter2D, of the full plane for GaussianBlur): they evaluate
+// their windows directly instead of reading the tile -- a perimeter's worth of extra remaps.
+namespace {
+constexpr int CUX = 32, CUY = 8;                       // quads per workgroup
+constexpr int CTW = 2 * CUX + 4, CTH = 2 * CUY + 4;    // green tile in px: 68 x 20
+constexpr int CSW = CUX + 2, CSH = CUY + 2;            // channel samples (quarter plane): 34 x 10
+}
+template <int O>
+__global__ void __launch_bounds__(256) k_ca_upsample_fused(const float* __restrict__ bayer, const float* __restrict__ g_full, CaGeom g,
+                                                           const float* __restrict__ quad, float wb, float* __restrict__ out) {
+    __shared__ float s_gat[CTH][CTW];
+    __shared__ float s_sub[CSH][CSW];
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int tid = threadIdx.x, q0x = tbx * CUX, q0y = tby * CUY;
+    const int H = g.H, W = g.W, h = g.h, w = g.w;
+    auto gat = [&](int Y, int X) {                      // remapped green at an in-image pixel
+        float mx, my;
+        ca_map(quad, g, Y, X, mx, my);
+        return remap_linear_px(g_full, H, W, mx, my);
+    };
+    {   // tile of remapped green in three sweeps over a thread's cells, so that every sweep's loads are in flight together:
+        // coordinate field, then the four taps, then the blend (remap_linear_px split in two)
+        constexpr int NC = (CTH * CTW + 255) / 256;
+        float mx[NC], my[NC];
+        bool in[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            int idx = tid + k * 256;
+            int ty = idx / CTW, tx = idx - ty * CTW;
+            int Y = 2 * q0y - 2 + ty, X = 2 * q0x - 2 + tx;
+            in[k] = idx < CTH * CTW && (unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W;
+            mx[k] = 0.0f; my[k] = 0.0f;
+            if (in[k]) ca_map(quad, g, Y, X, mx[k], my[k]);
+        }
+        float v[NC][4], fx[NC], fy[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            int sx = (int)rintf(mx[k] * 32.0f), sy = (int)rintf(my[k] * 32.0f);
+            int ix = sx >> 5, iy = sy >> 5;
+            fx[k] = (float)(sx & 31) * (1.0f / 32.0f); fy[k] = (float)(sy & 31) * (1.0f / 32.0f);
+            // clipped coordinates: (iy, ix) is inside the image, only the +1 neighbours can fall outside (BORDER_CONSTANT 0)
+            bool x1 = ix + 1 < W, y1 = iy + 1 < H;
+            const float* p0 = g_full + (size_t)iy * W + ix;
+            const float* p1 = g_full + (size_t)(y1 ? iy + 1 : iy) * W + ix;
+            v[k][0] = in[k] ? p0[0] : 0.0f;
+            v[k][1] = (in[k] && x1) ? p0[1] : 0.0f;
+            v[k][2] = (in[k] && y1) ? p1[0] : 0.0f;
+            v[k][3] = (in[k] && y1 && x1) ? p1[1] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            int idx = tid + k * 256;
+            if (idx < CTH * CTW) {
+                float wx0 = 1.0f - fx[k], wy0 = 1.0f - fy[k];
+                float r = ((v[k][0] * (wy0 * wx0) + v[k][1] * (wy0 * fx[k])) + v[k][2] * (fy[k] * wx0)) + v[k][3] * (fy[k] * fx[k]);
+                int ty = idx / CTW, tx = idx - ty * CTW;
+                s_gat[ty][tx] = in[k] ? r : 0.0f;
+            }
+        }
+        constexpr int NS = (CSH * CSW + 255) / 256;
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            int idx = tid + k * 256;
+            if (idx < CSH * CSW) {
+                int sy = idx / CSW, sx = idx - sy * CSW;
+                int a = q0y - 1 + sy, c = q0x - 1 + sx;
+                s_sub[sy][sx] = ((unsigned)a < (unsigned)h && (unsigned)c < (unsigned)w) ? bayer[(size_t)(2 * a + O) * W + 2 * c + O] * wb : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    const int lqy = tid / CUX, lqx = tid - lqy * CUX;
+    const int i = q0y + lqy, j = q0x + lqx;
+    if (i >= h || j >= w) return;
+    Win3 wg, wd;
+    float Wn[4][4];
+    if (i >= 1 && i <= h - 2 && j >= 1 && j <= w - 2) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float gs = s_gat[2 * (lqy + r) + O][2 * (lqx + c) + O];       // tile px of quad (i-1+r, j-1+c), site O
+                wg.v[r][c] = gs;
+                wd.v[r][c] = s_sub[lqy + r][lqx + c] - gs;                    // channel_diff (eag.py:142)
+            }
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) Wn[r][c] = s_gat[2 * lqy + 1 + r][2 * lqx + 1 + c];
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < 3; r++)
+#pragma unroll 1
+            for (int c = 0; c < 3; c++) {                                      // REFLECT_101 of the quarter planes
+                int a = b_101(i - 1 + r, h), cc = b_101(j - 1 + c, w);
+                float gs = gat(2 * a + O, 2 * cc + O);
+                wg.v[r][c] = gs;
+                wd.v[r][c] = bayer[(size_t)(2 * a + O) * W + 2 * cc + O] * wb - gs;
+            }
+#pragma unroll 1
+        for (int r = 0; r < 4; r++)
+#pragma unroll 1
+            for (int c = 0; c < 4; c++) Wn[r][c] = gat(b_101(2 * i - 1 + r, H), b_101(2 * j - 1 + c, W));   // REFLECT_101 at full resolution
+    }
+    float hf[4], fg[4], fd[4];
+    highpass_quad(Wn, hf);
+    if (O == 0) { filt_base_tl(wg, fg); filt_base_tl(wd, fd); } else { filt_base_br(wg, fg); filt_base_br(wd, fd); }
+    *reinterpret_cast<float2*>(out + (size_t)(2 * i) * W + 2 * j) = make_float2(fd[0] + (fg[0] + hf[0]), fd[1] + (fg[1] + hf[1]));
+    *reinterpret_cast<float2*>(out + (size_t)(2 * i + 1) * W + 2 * j) = make_float2(fd[2] + (fg[2] + hf[2]), fd[3] + (fg[3] + hf[3]));
+}
+int launch_ca_upsample_fused(hipStream_t st, const float* bayer, const float* g_full, int H, int W, const float* d_quad, int pos, float wb, float* out) {
+    if (pos != 0 && pos != 3) return -1;
+    dim3 grid((W / 2 + CUX - 1) / CUX, (H / 2 + CUY - 1) / CUY);
+    if (pos == 0) hipLaunchKernelGGL(k_ca_upsample_fused<0>, grid, dim3(256), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
+    else hipLaunchKernelGGL(k_ca_upsample_fused<1>, grid, dim3(256), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
     return CHECK_LAUNCH();
 }
 int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* bayer) {

@@ -56,8 +56,7 @@ int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,
                       double cyn, float scale, const float* d_lanczos_tab, int row0, int row1);
 int launch_ca_green(hipStream_t st, const float* bayer, int H, int W, float* out);
-int launch_ca_upsample(hipStream_t st, const float* bayer, const float* g_at, int H, int W, int pos, float wb, float* out);
-int launch_ca_remap_full(hipStream_t st, const float* src, int H, int W, const float* d_quad, float* dst);
+int launch_ca_upsample_fused(hipStream_t st, const float* bayer, const float* g_full, int H, int W, const float* d_quad, int pos, float wb, float* out);
 int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* bayer);
 int launch_warp_src_rows(hipStream_t st, int H, int W, const double* coeffs, int planes, double cxn, double cyn, float scale, int row0, int row1,
                          int* d_rows);
