@@ -352,10 +352,15 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 //   r' = med5(r-g)+g ; b' = med5(b-g)+g ; g' = (med5(g-r') + med5(g-b') + r' + b') / 2
 // cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.  Tile 64x32 px, halo 4 px.
 namespace {
-constexpr int BTX = 32, BTY = 32;
+#ifndef MED_BTX
+#define MED_BTX 64                               // measured (24 MP, 1 stage): 32x32/256 threads 0.410 ms, 64x32/512 0.405,
+#define MED_BTY 32                               // 64x16/256 0.432, 32x64/512 0.414, 64x64/1024 0.478, 128x32/1024 0.467
+#define MED_NT 512
+#endif
+constexpr int BTX = MED_BTX, BTY = MED_BTY;
 constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // r-g, b-g planes (halo 4)
 constexpr int B2X = BTX + 4, B2Y = BTY + 4;     // g-r', g-b' planes (halo 2)
-constexpr int NT_B = 256;
+constexpr int NT_B = MED_NT;
 
 // Median of 25 by a selection network (exact; order independent): the classic 99-exchange network;
 // wherever three exchanges (b,c),(a,c),(a,b) fully sort a triple they are issued as one v_min3 / v_med3 /
