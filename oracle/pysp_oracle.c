@@ -274,10 +274,16 @@ int orc_gaussian_blur3(const float *src, int h, int w, float *dst) {
 
 /* cv2.filter2D(x,-1,k3x3) float32 image, float64 kernel (eag.py:141,143): correlation, centre anchor,
  * BORDER_REFLECT_101, kernel cast to float32, non-zero taps only, accumulated in row-major order
- * starting from 0.0f, every product and sum rounded to float32. */
+ * starting from 0.0f, every product and sum rounded to float32.
+ * A tap whose weight is a power of two (16 of the 25 taps of get_rgbg_kernel: 1/64, 4/64, 16/64) has an exact
+ * product, so accumulating it with one fmaf() gives the same bits as multiply-then-add -- except when the product
+ * falls below 2^-126, where the separate multiply would round it first.  The restatement defines those taps as the
+ * exact (fmaf) form, which is what lets the HIP kernels issue them as a single instruction. */
+static inline int is_pow2f(float k) { int e; return frexpf(fabsf(k), &e) == 0.5f; }
 int orc_filter2d_3x3(const float *src, int h, int w, const double k[9], float *dst) {
     float kf[9];
-    for (int i = 0; i < 9; i++) kf[i] = (float)k[i];
+    int p2[9];
+    for (int i = 0; i < 9; i++) { kf[i] = (float)k[i]; p2[i] = is_pow2f(kf[i]); }
 #pragma omp parallel for
     for (int y = 0; y < h; y++) {
         const float *rows[3] = {src + (size_t)b_101(y - 1, h) * w, src + (size_t)y * w,
@@ -286,7 +292,7 @@ int orc_filter2d_3x3(const float *src, int h, int w, const double k[9], float *d
             int xs[3] = {b_101(x - 1, w), x, b_101(x + 1, w)};
             float s = 0.0f;
             for (int t = 0; t < 9; t++)
-                if (kf[t] != 0.0f) s = s + kf[t] * rows[t / 3][xs[t % 3]];
+                if (kf[t] != 0.0f) s = p2[t] ? fmaf(kf[t], rows[t / 3][xs[t % 3]], s) : s + kf[t] * rows[t / 3][xs[t % 3]];
             dst[(size_t)y * w + x] = s;
         }
     }

@@ -50,36 +50,41 @@ DEVI Win3 load_win(const float* plane, int gy, int gx) {
 
 // cv2.filter2D with the four photosite kernels of get_rgbg_kernel (gaussian.py:19-54): non-zero taps
 // in row-major order, accumulated from 0.0f.  o[0..3] = TL, TR, BL, BR target pixel of the quad.
+// 16 of the 25 taps are powers of two (1/64, 4/64, 16/64): their product with the sample is exact, so
+// fmaf(k, v, s) rounds once to the very value "s + k*v" rounds to -- P2() spells those taps as one FMA
+// (bit-identical, one instruction instead of two; only a product below 2^-126 could tell the two apart).
+#define P2(k, v) s = __builtin_fmaf(k, v, s)
 DEVI void filt_base_tl(const Win3& w, float o[4]) {  // base position TOP_LEFT (red)
     float s;
-    s = 0.0f; s = s + 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; s = s + 0.015625f * w.v[0][2];
+    s = 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; P2(0.015625f, w.v[0][2]);
     s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
-    s = s + 0.015625f * w.v[2][0]; s = s + 0.09375f * w.v[2][1]; s = s + 0.015625f * w.v[2][2];
+    P2(0.015625f, w.v[2][0]); s = s + 0.09375f * w.v[2][1]; P2(0.015625f, w.v[2][2]);
     o[0] = s;
-    s = 0.0f; s = s + 0.0625f * w.v[0][1]; s = s + 0.0625f * w.v[0][2]; s = s + 0.375f * w.v[1][1];
-    s = s + 0.375f * w.v[1][2]; s = s + 0.0625f * w.v[2][1]; s = s + 0.0625f * w.v[2][2];
+    s = 0.0625f * w.v[0][1]; P2(0.0625f, w.v[0][2]); s = s + 0.375f * w.v[1][1];
+    s = s + 0.375f * w.v[1][2]; P2(0.0625f, w.v[2][1]); P2(0.0625f, w.v[2][2]);
     o[1] = s;
-    s = 0.0f; s = s + 0.0625f * w.v[1][0]; s = s + 0.375f * w.v[1][1]; s = s + 0.0625f * w.v[1][2];
-    s = s + 0.0625f * w.v[2][0]; s = s + 0.375f * w.v[2][1]; s = s + 0.0625f * w.v[2][2];
+    s = 0.0625f * w.v[1][0]; s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[1][2]);
+    P2(0.0625f, w.v[2][0]); s = s + 0.375f * w.v[2][1]; P2(0.0625f, w.v[2][2]);
     o[2] = s;
-    s = 0.0f; s = s + 0.25f * w.v[1][1]; s = s + 0.25f * w.v[1][2]; s = s + 0.25f * w.v[2][1]; s = s + 0.25f * w.v[2][2];
+    s = 0.25f * w.v[1][1]; P2(0.25f, w.v[1][2]); P2(0.25f, w.v[2][1]); P2(0.25f, w.v[2][2]);
     o[3] = s;
 }
 DEVI void filt_base_br(const Win3& w, float o[4]) {  // base position BOTTOM_RIGHT (blue)
     float s;
-    s = 0.0f; s = s + 0.25f * w.v[0][0]; s = s + 0.25f * w.v[0][1]; s = s + 0.25f * w.v[1][0]; s = s + 0.25f * w.v[1][1];
+    s = 0.25f * w.v[0][0]; P2(0.25f, w.v[0][1]); P2(0.25f, w.v[1][0]); P2(0.25f, w.v[1][1]);
     o[0] = s;
-    s = 0.0f; s = s + 0.0625f * w.v[0][0]; s = s + 0.375f * w.v[0][1]; s = s + 0.0625f * w.v[0][2];
-    s = s + 0.0625f * w.v[1][0]; s = s + 0.375f * w.v[1][1]; s = s + 0.0625f * w.v[1][2];
+    s = 0.0625f * w.v[0][0]; s = s + 0.375f * w.v[0][1]; P2(0.0625f, w.v[0][2]);
+    P2(0.0625f, w.v[1][0]); s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[1][2]);
     o[1] = s;
-    s = 0.0f; s = s + 0.0625f * w.v[0][0]; s = s + 0.0625f * w.v[0][1]; s = s + 0.375f * w.v[1][0];
-    s = s + 0.375f * w.v[1][1]; s = s + 0.0625f * w.v[2][0]; s = s + 0.0625f * w.v[2][1];
+    s = 0.0625f * w.v[0][0]; P2(0.0625f, w.v[0][1]); s = s + 0.375f * w.v[1][0];
+    s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[2][0]); P2(0.0625f, w.v[2][1]);
     o[2] = s;
-    s = 0.0f; s = s + 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; s = s + 0.015625f * w.v[0][2];
+    s = 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; P2(0.015625f, w.v[0][2]);
     s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
-    s = s + 0.015625f * w.v[2][0]; s = s + 0.09375f * w.v[2][1]; s = s + 0.015625f * w.v[2][2];
+    P2(0.015625f, w.v[2][0]); s = s + 0.09375f * w.v[2][1]; P2(0.015625f, w.v[2][2]);
     o[3] = s;
 }
+#undef P2
 
 // g - GaussianBlur3(g) on the 4x4 full-resolution window around a quad (ahd.py:120-121)
 DEVI void highpass_quad(const float W[4][4], float hf[4]) {
