@@ -137,6 +137,9 @@ int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, co
 /* General form: tail 0 = pysp_demosaic_dev, 1 = + to_lin_srgb (clip + CCM; BASELINE config 3 "debayer + WB + CCM"),
  * 2 = pysp_pipeline_srgb_dev, 3 = with x/(1+x) in between. */
 int pysp_pipeline_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *d_out);
+/* A batch of frames that share camera parameters (BASELINE config 3: the frames one rank owns): n_frames device mosaics ->
+ * n_frames device images, enqueued back to back on the context's stream with one call. */
+int pysp_pipeline_batch_dev(pysp_ctx *ctx, const float *const *d_bayers, int n_frames, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *const *d_outs);
 
 /* The same pipelines fed by the raw uint16 mosaic: normalization.py:4-24 (clip(x-black_c,0,sat_c)/sat_c, CFA
  * sites indexed r,g1,b,g2) is fused into the tile loader, so the float32 mosaic never exists in memory

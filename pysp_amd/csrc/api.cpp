@@ -420,6 +420,14 @@ int pysp_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const f
     if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline: tail must be 0..3");
     return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, tail, d_out);
 }
+int pysp_pipeline_batch_dev(pysp_ctx* ctx, const float* const* d_bayers, int n_frames, int H, int W, const float wb[3], const double M[9], int quality,
+                            int hdr, int stages, int tail, float* const* d_outs) {
+    CTX_ENTER(ctx);
+    if (n_frames < 0 || (n_frames > 0 && (!d_bayers || !d_outs))) return fail(PYSP_EBADARG, "pipeline_batch: bad frame list");
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_batch: tail must be 0..3");
+    for (int i = 0; i < n_frames; i++) TRY(run_pipeline_dev(ctx, d_bayers[i], H, W, wb, M, quality, hdr, stages, tail, d_outs[i]));
+    return PYSP_OK;
+}
 int pysp_pipeline_u16_dev(pysp_ctx* ctx, const uint16_t* d_bayer, int H, int W, const float black[4], const float sat[4], const float wb[3],
                           const double M[9], int quality, int hdr, int stages, int tail, float* d_out) {
     CTX_ENTER(ctx);

@@ -58,6 +58,22 @@ class DevicePipeline:
                                                  int(reinhard), _dp(out)))
         return out
 
+    def batch(self, bayers: Sequence, wb, M, quality: int = _lib.QUALITY_FAST, hdr: bool = False, stages: int = 1, tail: int = 1, outs=None):
+        """Frames that share camera parameters in one library call (BASELINE config 3 per rank); tail as in `raw_u16_to_rgb`."""
+        if not bayers:
+            return []
+        H, W = self._check_bayer(bayers[0])
+        for b in bayers:
+            if self._check_bayer(b) != (H, W):
+                raise ValueError("all frames of a batch must share one shape")
+        outs = [self.torch.empty((H, W, 3), dtype=self.torch.float32, device=self.device) for _ in bayers] if outs is None else outs
+        n = len(bayers)
+        src = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bayers])
+        dst = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+        self._enter()
+        _lib.check(self.L.pysp_pipeline_batch_dev(self.ctx.handle, src, n, H, W, _lib.wb3(wb), _lib.mat9(M), int(quality), int(hdr), int(stages), int(tail), dst))
+        return outs
+
     def raw_u16_to_rgb(self, raw_u16, black, sat, wb, M, quality: int = _lib.QUALITY_BEST, stages: int = 1, tail: int = 2, out=None):
         """uint16 sensor mosaic -> normalise (normalization.py:4-24, fused into the tile loader) -> demosaic ->
         colour tail (0 camera RGB, 1 linear sRGB, 2 sRGB, 3 Reinhard + sRGB).  2 B/px of input traffic."""

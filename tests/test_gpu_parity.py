@@ -348,6 +348,15 @@ def test_config3_batch_eag_device_resident(orc, wbobj):
     for i, o in outs:
         u = ulp_diff(o.cpu().numpy(), orc.pipeline_srgb(rggb_frame(H, W, 1000 + i), wb, M, 1, False, 0, False))
         assert u.max() <= 1 and np.mean(u != 0) < 1e-4
+    # the same shard through the batch entry point (one library call), EAG + WB + CCM = config 3's per-frame work
+    frames = [torch.from_numpy(rggb_frame(H, W, 1000 + i)).cuda() for i in mine]
+    lin = pipe.batch(frames, wb, M, quality=_lib.QUALITY_FAST, tail=1)
+    pipe.sync()
+    for i, o in zip(mine, lin):
+        assert np.array_equal(o.cpu().numpy(), orc.cam_to_rgb(orc.demosaic_eag(rggb_frame(H, W, 1000 + i), wb), M, True))
+    assert pipe.batch([], wb, M) == []
+    with pytest.raises(ValueError):
+        pipe.batch([frames[0], frames[1][:100].contiguous()], wb, M)
 
 
 def test_config4_hdr_stack_device_resident(orc, wbobj):
