@@ -53,33 +53,34 @@ DEVI Win3 load_win(const float* plane, int gy, int gx) {
 // 16 of the 25 taps are powers of two (1/64, 4/64, 16/64): their product with the sample is exact, so
 // fmaf(k, v, s) rounds once to the very value "s + k*v" rounds to -- P2() spells those taps as one FMA
 // (bit-identical, one instruction instead of two; only a product below 2^-126 could tell the two apart).
+// Every sum starts from +0.0f like the oracle's, so an all-(-0) window still gives +0.
 #define P2(k, v) s = __builtin_fmaf(k, v, s)
 DEVI void filt_base_tl(const Win3& w, float o[4]) {  // base position TOP_LEFT (red)
     float s;
-    s = 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; P2(0.015625f, w.v[0][2]);
+    s = 0.0f; P2(0.015625f, w.v[0][0]); s = s + 0.09375f * w.v[0][1]; P2(0.015625f, w.v[0][2]);
     s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
     P2(0.015625f, w.v[2][0]); s = s + 0.09375f * w.v[2][1]; P2(0.015625f, w.v[2][2]);
     o[0] = s;
-    s = 0.0625f * w.v[0][1]; P2(0.0625f, w.v[0][2]); s = s + 0.375f * w.v[1][1];
+    s = 0.0f; P2(0.0625f, w.v[0][1]); P2(0.0625f, w.v[0][2]); s = s + 0.375f * w.v[1][1];
     s = s + 0.375f * w.v[1][2]; P2(0.0625f, w.v[2][1]); P2(0.0625f, w.v[2][2]);
     o[1] = s;
-    s = 0.0625f * w.v[1][0]; s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[1][2]);
+    s = 0.0f; P2(0.0625f, w.v[1][0]); s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[1][2]);
     P2(0.0625f, w.v[2][0]); s = s + 0.375f * w.v[2][1]; P2(0.0625f, w.v[2][2]);
     o[2] = s;
-    s = 0.25f * w.v[1][1]; P2(0.25f, w.v[1][2]); P2(0.25f, w.v[2][1]); P2(0.25f, w.v[2][2]);
+    s = 0.0f; P2(0.25f, w.v[1][1]); P2(0.25f, w.v[1][2]); P2(0.25f, w.v[2][1]); P2(0.25f, w.v[2][2]);
     o[3] = s;
 }
 DEVI void filt_base_br(const Win3& w, float o[4]) {  // base position BOTTOM_RIGHT (blue)
     float s;
-    s = 0.25f * w.v[0][0]; P2(0.25f, w.v[0][1]); P2(0.25f, w.v[1][0]); P2(0.25f, w.v[1][1]);
+    s = 0.0f; P2(0.25f, w.v[0][0]); P2(0.25f, w.v[0][1]); P2(0.25f, w.v[1][0]); P2(0.25f, w.v[1][1]);
     o[0] = s;
-    s = 0.0625f * w.v[0][0]; s = s + 0.375f * w.v[0][1]; P2(0.0625f, w.v[0][2]);
+    s = 0.0f; P2(0.0625f, w.v[0][0]); s = s + 0.375f * w.v[0][1]; P2(0.0625f, w.v[0][2]);
     P2(0.0625f, w.v[1][0]); s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[1][2]);
     o[1] = s;
-    s = 0.0625f * w.v[0][0]; P2(0.0625f, w.v[0][1]); s = s + 0.375f * w.v[1][0];
+    s = 0.0f; P2(0.0625f, w.v[0][0]); P2(0.0625f, w.v[0][1]); s = s + 0.375f * w.v[1][0];
     s = s + 0.375f * w.v[1][1]; P2(0.0625f, w.v[2][0]); P2(0.0625f, w.v[2][1]);
     o[2] = s;
-    s = 0.015625f * w.v[0][0]; s = s + 0.09375f * w.v[0][1]; P2(0.015625f, w.v[0][2]);
+    s = 0.0f; P2(0.015625f, w.v[0][0]); s = s + 0.09375f * w.v[0][1]; P2(0.015625f, w.v[0][2]);
     s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
     P2(0.015625f, w.v[2][0]); s = s + 0.09375f * w.v[2][1]; P2(0.015625f, w.v[2][2]);
     o[3] = s;

@@ -852,3 +852,14 @@ def test_c_client_runs_on_gpu(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("ok (GPU"), out.stdout + out.stderr
     assert "0.5 0.25 0.357143" in out.stdout          # Draft of a flat 0.25 mosaic times wb = (2, 1, 1/0.7)
+
+
+def test_signed_zero_bits_match_oracle(orc, wbobj):
+    """-0.0 samples: the filters accumulate from +0.0f in oracle and kernels alike, so even the sign bit of a zero result agrees."""
+    from pysp_amd.const import QualityDemosaic
+    wb, M = _wbM(orc)
+    bay = np.full((8, 12), -0.0, np.float32)
+    bay[2:4, 4:8] = 0.25
+    for q, ref in ((QualityDemosaic.Fast, orc.demosaic_eag(bay, wb)), (QualityDemosaic.Best, orc.demosaic_ahd(bay, wb, M, False, 1))):
+        got = _raw(bay.copy(), wbobj).demosaic(q).image
+        assert got.tobytes() == ref.tobytes(), q
