@@ -145,7 +145,7 @@ static void lab_build(float (*tab)[4], int n, int nb, int loexp, double (*fn)(do
         tab[i][0] = (float)g0;
         tab[i][1] = (float)((-3.0 * g0 + 4.0 * gm - g1) / h);
         tab[i][2] = (float)((2.0 * g0 - 4.0 * gm + 2.0 * g1) / (h * h));
-        tab[i][3] = 0.0f;
+        tab[i][3] = (float)x0;   /* segment start, = x with its low S bits cleared for every x of the segment */
     }
 }
 __attribute__((constructor)) static void lab_tables_init(void) {

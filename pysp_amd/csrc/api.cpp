@@ -95,7 +95,7 @@ void fill_segments(float* out, int count, int nb, int loexp, F f) {
         out[0] = (float)f0;
         out[1] = (float)((-3.0 * f0 + 4.0 * fm - f1) / w);
         out[2] = (float)((2.0 * f0 - 4.0 * fm + 2.0 * f1) / (w * w));
-        out[3] = 0.0f;
+        out[3] = (float)lo;   // segment start: lets a lookup take x - x_i from the entry instead of masking the argument's bits
     }
 }
 }  // namespace

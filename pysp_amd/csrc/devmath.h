@@ -71,8 +71,8 @@ DEVI float ccm_row(const double* m, float r, float g, float b) {
 // [2^-7,2)); api.cpp builds them once per context (lab_tables.h) and the AHD kernel keeps a copy in LDS.
 // The LDS copy is laid out so that the slot is a plain bit field of the float: slot = (bits >> S) & (SLOTS-1)
 // (LAB_*_SLOTS in lab_tables.h), which makes every bit pattern -- also the ones whose lookup is discarded by
-// the range select, and NaN -- address the table itself.  A lookup is then shift, and (address), and, sub
-// (exact offset inside the segment), one 12-byte LDS read and two FMAs.
+// the range select, and NaN -- address the table itself.  A lookup is then shift, and (address), one 16-byte LDS read
+// (a, b, c and the segment start x_i), one exact subtraction and two FMAs.
 #include "lab_tables.h"
 struct LabTab { const float4* dec; const float4* cb; };
 template <int NB, int SLOTS>
@@ -81,7 +81,7 @@ DEVI float lab_lut(const float4* tab, float x) {
     static_assert(S > 4, "the byte offset is taken with one shift");
     int bits = __float_as_int(x);
     float4 e = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tab) + ((bits >> (S - 4)) & ((SLOTS - 1) << 4)));
-    float fr = x - __int_as_float(bits & ~((1 << S) - 1));
+    float fr = x - e.w;   // e.w = the segment's start x_i (the argument with its low S bits cleared): exact, and one integer op less than masking
     return __builtin_fmaf(__builtin_fmaf(e.z, fr, e.y), fr, e.x);
 }
 DEVI float lab_decode(LabTab t, float v) {

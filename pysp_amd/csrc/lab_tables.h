@@ -1,7 +1,7 @@
 // lab_tables.h -- the two lookup tables behind the restated float32 RGB->Lab (devmath.h).
 //
 // f(x) is approximated on each segment [x_i, x_{i+1}) by the parabola through f(x_i), f(midpoint), f(x_{i+1}),
-// stored as (a, b, c, 0) with f ~ a + b*s + c*s^2, s = x - x_i.  Segment boundaries are the floats whose low
+// stored as (a, b, c, x_i) with f ~ a + b*s + c*s^2, s = x - x_i.  Segment boundaries are the floats whose low
 // 23-NB mantissa bits are zero, so the segment index and x_i come straight from the bit pattern of x.
 // Coefficients are computed in float64 with libm and cast to float32; tests/test_abi_cpu.py checks that the
 // tables equal the CPU oracle's (an independent build of the same definition) bit for bit.
