@@ -212,7 +212,7 @@ def main() -> None:
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(per_kernel[dom], 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
                     "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "AHD is VALU-issue bound (725 + 620 wave-level instructions per pixel in the two kernels vs 16 B/px, one every 4.2 cycles per SIMD, profiles/r1_v12_pmc_summary.csv); the HBM fraction is reported as required, not expected to approach 1"}
+                    "note": "AHD is VALU-issue bound (710 + 620 wave-level instructions per pixel in the two kernels vs 16 B/px, one every 4.1 cycles per SIMD, profiles/r1_v13_pmc_summary.csv); the HBM fraction is reported as required, not expected to approach 1"}
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline and quality >= 0:
