@@ -112,8 +112,6 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
     }
 }
 
-static_assert(12 * TQX * TQY <= 4 * MWY * MWX + 4 * GY * GX, "rgb_h stash must fit in the dead planes");
-
 }  // namespace
 
 struct AhdParams {
@@ -130,13 +128,15 @@ struct AhdParams {
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
 template <bool TINY, bool U16>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
-    // planes: mosaic (dead after P1), then green/difference planes direction-major (direction 0 dead after its
-    // P2).  The front of this array is reused for the horizontal RGB candidates while the vertical pass runs.
-    __shared__ __attribute__((aligned(16))) float planes[4 * MWY * MWX + 8 * GY * GX];
+    // LDS: the mosaic planes are dead once P1 and the green reads below are done, so the Lab buffer of the direction loop
+    // lies over them (a barrier separates the last mosaic read from the first Lab write); green/difference planes follow,
+    // direction-major.  38.4 KB per workgroup in total: four workgroups per CU.
+    constexpr int NLAB = 3 * LPR * LPS, NMW = 4 * MWY * MWX, NFRONT = NLAB > NMW ? NLAB : NMW;
+    static_assert(NFRONT % 4 == 0, "the g/D planes start 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) float planes[NFRONT + 8 * GY * GX];
     float* const mw = planes;
-    float* const gq = planes + 4 * MWY * MWX;
-    float* const rgbh_lds = planes;                  // [12][TQY*TQX], needs 12*420 floats <= 4*MWY*MWX + 4*GY*GX
-    __shared__ __attribute__((aligned(16))) float lab[3 * LPR * LPS];   // 31.9 KB, one direction at a time
+    float* const lab = planes;                       // [3][LPR][LPS], one direction at a time
+    float* const gq = planes + NFRONT;
     __shared__ __attribute__((aligned(16))) unsigned short vmap[MPR * MPS];   // 4.6 KB, votes: h | v << 8
     __shared__ float4 s_labtab[LAB_SLOTS];                                  // 12 KB
     const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
@@ -210,16 +210,17 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     // vote-map cell of this quad's top-left pixel (map origin = tile origin - 1 px)
     const int vmy = 2 * lqy - 1, vmx = 2 * lqx - 1;
 
-    float rgbv[4][3];
+    float rgbh[4][3], rgbv[4][3];   // both candidates stay in registers until the selection
     const bool inner = active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX;
-    const int oq = (lqy - 1) * TQX + (lqx - 1);      // index of this quad among the tile's output quads
     float g1_l = 0, g1_c = 0, g1_dl = 0, g1_d = 0, g2_u = 0, g2_ur = 0, g2_c = 0, g2_r = 0;
     if (active) {   // green samples of the 4x4 window, shared by both directions
         g1_l = MWAT(P_G1, my, mx - 1); g1_c = MWAT(P_G1, my, mx); g1_dl = MWAT(P_G1, my + 1, mx - 1); g1_d = MWAT(P_G1, my + 1, mx);
         g2_u = MWAT(P_G2, my - 1, mx); g2_ur = MWAT(P_G2, my - 1, mx + 1); g2_c = MWAT(P_G2, my, mx); g2_r = MWAT(P_G2, my, mx + 1);
     }
 
-#pragma unroll 1
+    // fully unrolled: plane offsets and the vote's direction become constants, and the register allocator does much better
+    // on the two straight-line copies (93 VGPRs) than on the loop (137)
+#pragma unroll
     for (int dir = 0; dir < 2; dir++) {
         float labq[4][3], rgbc[4][3];
         // ---- P2
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 #endif
             }
         }
-        if (dir == 1) __syncthreads();   // votes of direction 0 are done reading the Lab buffer
+        __syncthreads();   // direction 0: every thread has read its mosaic samples; direction 1: the votes of direction 0 are done with the Lab buffer
         if (active) {
             // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring)
 #pragma unroll
@@ -279,20 +280,10 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             }
         }
         __syncthreads();
-        // every thread is past P2 of this direction: the mosaic planes and this direction's g/D planes are dead
-        if (dir == 0) {
-            if (inner) {
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) rgbh_lds[(k * 3 + c) * (TQX * TQY) + oq] = rgbc[k][c];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) rgbv[k][c] = rgbc[k][c];
-        }
+            for (int c = 0; c < 3; c++) { if (dir == 0) rgbh[k][c] = rgbc[k][c]; else rgbv[k][c] = rgbc[k][c]; }
 
         // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 window
         if (active) {
@@ -337,9 +328,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             unsigned int s = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
             unsigned int sh = s & 0xFFu, sv = s >> 8;
             float c = sh < sv ? 1.0f : 0.0f, nc = 1.0f - c;            // ahd.py:139-145, literally
-            float r = rgbh_lds[(k * 3 + 0) * (TQX * TQY) + oq] * c + rgbv[k][0] * nc;
-            float g = rgbh_lds[(k * 3 + 1) * (TQX * TQY) + oq] * c + rgbv[k][1] * nc;
-            float b = rgbh_lds[(k * 3 + 2) * (TQX * TQY) + oq] * c + rgbv[k][2] * nc;
+            float r = rgbh[k][0] * c + rgbv[k][0] * nc;
+            float g = rgbh[k][1] * c + rgbv[k][1] * nc;
+            float b = rgbh[k][2] * c + rgbv[k][2] * nc;
             colour_tail(p.tail, M, r, g, b);
             float* o = p.out + ((size_t)(2 * qi + dy) * W + (2 * qj + dx)) * 3;
             o[0] = r; o[1] = g; o[2] = b;
