@@ -39,7 +39,6 @@ constexpr int NT_A = LQX * LQY;                    // 512: one thread per quad o
 constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // ahd.py:89-94
 
 enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
-enum { Q_GHR = 0, Q_GHB, Q_DHR, Q_DHB, Q_GVR, Q_GVB, Q_DVR, Q_DVB };   // direction-major
 
 // ahd.py:32-62: second white balance, CCM without clip, (HDR: luma + x/(1+x)), Lab
 DEVI void homog_lab(LabTab lt, float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, float& A, float& Bq) {
@@ -128,17 +127,21 @@ struct AhdParams {
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
 template <bool TINY, bool U16>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
-    // LDS: the mosaic planes are dead once P1 and the green reads below are done, so the Lab buffer of the direction loop
-    // lies over them (a barrier separates the last mosaic read from the first Lab write); green/difference planes follow,
-    // direction-major.  38.4 KB per workgroup in total: four workgroups per CU.
-    constexpr int NLAB = 3 * LPR * LPS, NMW = 4 * MWY * MWX, NFRONT = NLAB > NMW ? NLAB : NMW;
-    static_assert(NFRONT % 4 == 0, "the g/D planes start 16-byte aligned");
-    __shared__ __attribute__((aligned(16))) float planes[NFRONT + 8 * GY * GX];
+    // LDS, 30.6 KB per workgroup (five workgroups per CU).  The mosaic planes are dead once P1 and the green reads below are
+    // done, and the horizontal g/D planes once the horizontal P2 is: the Lab buffer of both directions lies over them (a barrier
+    // separates the last read of either from the first Lab write).  The vertical g/D planes follow.  The packed vote map
+    // lives in the first 120 slots of the decode table, which no valid lookup addresses (segments start at slot 128).
+    constexpr int NLAB = 3 * LPR * LPS, NDEAD = 4 * MWY * MWX + 4 * GY * GX, NFRONT = NLAB > NDEAD ? NLAB : NDEAD;
+    static_assert(NFRONT % 4 == 0, "the vertical g/D planes start 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) float planes[NFRONT + 4 * GY * GX];
     float* const mw = planes;
     float* const lab = planes;                       // [3][LPR][LPS], one direction at a time
-    float* const gq = planes + NFRONT;
-    __shared__ __attribute__((aligned(16))) unsigned short vmap[MPR * MPS];   // 4.6 KB, votes: h | v << 8
+    float* const gq0 = planes + 4 * MWY * MWX;       // horizontal: GHR, GHB, DHR, DHB
+    float* const gq1 = planes + NFRONT;              // vertical:   GVR, GVB, DVR, DVB
     __shared__ float4 s_labtab[LAB_SLOTS];                                  // 12 KB
+    unsigned short* const vmap = reinterpret_cast<unsigned short*>(s_labtab);   // [MPR][MPS] votes: h | v << 8
+    static_assert(MPR * MPS * sizeof(unsigned short) <= (((127 + LAB_DEC_LOEXP) << LAB_DEC_NB) & (LAB_DEC_SLOTS - 1)) * sizeof(float4),
+                  "the vote map must end before the first used slot of the decode table");
     const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
 
     const int tid = threadIdx.x;
@@ -195,10 +198,10 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         float gvr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
         float ghb = (((MWAT(P_B, a, c - 1) * AH0 + MWAT(P_G2, a, c) * AH1) + bc * AH2) + MWAT(P_G2, a, c + 1) * AH1) + MWAT(P_B, a, c + 1) * AH0;
         float gvb = (((MWAT(P_B, a - 1, c) * AH0 + MWAT(P_G1, a, c) * AH1) + bc * AH2) + MWAT(P_G1, a + 1, c) * AH1) + MWAT(P_B, a + 1, c) * AH0;
-        gq[Q_GHR * GY * GX + idx] = ghr; gq[Q_GVR * GY * GX + idx] = gvr;
-        gq[Q_GHB * GY * GX + idx] = ghb; gq[Q_GVB * GY * GX + idx] = gvb;
-        gq[Q_DHR * GY * GX + idx] = rc - ghr; gq[Q_DVR * GY * GX + idx] = rc - gvr;
-        gq[Q_DHB * GY * GX + idx] = bc - ghb; gq[Q_DVB * GY * GX + idx] = bc - gvb;
+        gq0[0 * GY * GX + idx] = ghr; gq1[0 * GY * GX + idx] = gvr;
+        gq0[1 * GY * GX + idx] = ghb; gq1[1 * GY * GX + idx] = gvb;
+        gq0[2 * GY * GX + idx] = rc - ghr; gq1[2 * GY * GX + idx] = rc - gvr;
+        gq0[3 * GY * GX + idx] = bc - ghb; gq1[3 * GY * GX + idx] = bc - gvb;
     }
     __syncthreads();
 
@@ -225,10 +228,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         float labq[4][3], rgbc[4][3];
         // ---- P2
         if (active) {
-            const float* gR = gq + (4 * dir + 0) * GY * GX;
-            const float* gB = gq + (4 * dir + 1) * GY * GX;
-            const float* dR = gq + (4 * dir + 2) * GY * GX;
-            const float* dB = gq + (4 * dir + 3) * GY * GX;
+            const float* gqd = dir == 0 ? gq0 : gq1;
+            const float* gR = gqd, *gB = gqd + GY * GX, *dR = gqd + 2 * GY * GX, *dB = gqd + 3 * GY * GX;
             Win3 wgr = load_win<GX>(gR, gy, gx), wgb = load_win<GX>(gB, gy, gx);
             // full-resolution green, rows 2qi-1..2qi+2, cols 2qj-1..2qj+2
             float Wn[4][4] = {{wgb.v[0][0], g2_u, wgb.v[0][1], g2_ur},
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 #endif
             }
         }
-        __syncthreads();   // direction 0: every thread has read its mosaic samples; direction 1: the votes of direction 0 are done with the Lab buffer
+        __syncthreads();   // direction 0: every thread is done with the mosaic and horizontal g/D planes; direction 1: the votes of direction 0 are done with the Lab buffer
         if (active) {
             // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring)
 #pragma unroll
