@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
-ALG_BYTES_PER_PX = 16          # 4 B mosaic read + 12 B RGB written
+ALG_BYTES_PER_PX = 16          # the fused path: 4 B mosaic read + 12 B RGB written
+# per kernel: the select kernel reads the mosaic and writes RGB, a median stage reads and writes RGB
+KERNEL_ALG_BYTES_PER_PX = {"k_ahd_select": 16, "k_ahd_median_stage": 24}
 
 WORKLOADS = {
     # name: (H, W, quality, stages, description[, tail])   tail: 2 = to_lin_srgb + lin_srgb_to_srgb (default), 1 = to_lin_srgb only
@@ -195,7 +197,7 @@ def main() -> None:
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps * mp_per_frame / elapsed
     dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
-    alg_bytes = alg_bytes_per_px * H * W
+    alg_bytes = KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px) * H * W      # of the dominant kernel's own launch
     roofline = None
     traffic = None
     try:   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside the benchmark itself)
@@ -211,8 +213,9 @@ def main() -> None:
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(per_kernel[dom], 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
-                    "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "AHD is VALU-issue bound (710 + 620 wave-level instructions per pixel in the two kernels vs 16 B/px, one every 4.1 cycles per SIMD, profiles/r1_v13_pmc_summary.csv); the HBM fraction is reported as required, not expected to approach 1"}
+                    "alg_bytes_per_px": KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px),
+                    "pipeline_frac": round(alg_bytes_per_px * H * W / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": "AHD is VALU-issue bound (750 + 620 wave-level instructions per pixel in the two kernels vs 16 B/px for the path, one every 3.1 / 4.2 cycles per SIMD, profiles/r1_v14_pmc_summary.csv); pipeline_frac is the whole two-kernel step against the path's 16 B/px; the HBM fraction is reported as required, not expected to approach 1"}
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline and quality >= 0:
