@@ -342,12 +342,12 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 // ================================================================================================
 // Kernel B: one chroma post-process stage (ahd.py:148-161) + optional colour tail.
 //   r' = med5(r-g)+g ; b' = med5(b-g)+g ; g' = (med5(g-r') + med5(g-b') + r' + b') / 2
-// cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.  Tile 64x32 px, halo 4 px.
+// cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.  Tile 32x32 px, halo 4 px.
 namespace {
 #ifndef MED_BTX
-#define MED_BTX 64                               // measured (24 MP, 1 stage): 32x32/256 threads 0.410 ms, 64x32/512 0.405,
-#define MED_BTY 32                               // 64x16/256 0.432, 32x64/512 0.414, 64x64/1024 0.478, 128x32/1024 0.467
-#define MED_NT 512
+#define MED_BTX 32                               // measured (24 MP, 1 stage), with r', b' of the interior kept in registers:
+#define MED_BTY 32                               // 32x32 px / 256 threads (29.6 KB LDS, 5 workgroups per CU) 0.389 ms;
+#define MED_NT 256                               // 64x32 / 512 (54 KB, 2 per CU) 0.394; before, with r', b' in LDS: 0.402-0.410
 #endif
 constexpr int BTX = MED_BTX, BTY = MED_BTY;
 constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // r-g, b-g planes (halo 4)
@@ -413,7 +413,6 @@ DEVI void load_pair_window(const float* plane, int stride, int ly, int lx, float
 
 __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
     __shared__ __attribute__((aligned(16))) float s_g[B4Y][B4X], s_drg[B4Y][B4X], s_dbg[B4Y][B4X];   // g, r-g, b-g (halo 4)
-    __shared__ __attribute__((aligned(16))) float s_r1[B2Y][B2X], s_b1[B2Y][B2X];                     // r', b'      (halo 2)
     __shared__ __attribute__((aligned(16))) float s_d1[B2Y][B2X], s_d2[B2Y][B2X];                     // g-r', g-b'  (halo 2)
     const int tid = threadIdx.x, H = p.H, W = p.W;
     int tbx, tby;
@@ -442,24 +441,43 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         }
     }
     __syncthreads();
-    // r', b' and the second-level differences on the halo-2 region, two horizontally adjacent pixels per
-    // thread (W and the tile origin are even, so a pair is inside or outside the image as a whole).
-    for (int idx = tid; idx < B2Y * (B2X / 2); idx += NT_B) {
-        int oy = idx / (B2X / 2), ox = 2 * (idx - oy * (B2X / 2));
-        int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
-        if (y < 0 || y >= H || x < 0 || x >= W) continue;       // filled from the clamped position below
+    // First level: r' = med5(r-g)+g, b' = med5(b-g)+g and the second-level differences g-r', g-b' on the halo-2 region, two
+    // horizontally adjacent pixels per thread (W and the tile origin are even, so a pair is inside or outside the image as a
+    // whole).  A thread takes the same pairs of the tile's interior here as at the second level below, so their r', b' stay in
+    // registers (only the differences go to LDS); the halo-2 ring is shared out afterwards.
+    auto first_level = [&](int oy, int ox, float& r0, float& r1, float& b0, float& b1) {   // (oy, ox): pair position in the halo-2 region
         float w[5][6], m0, m1;
         load_pair_window(&s_drg[0][0], B4X, oy, ox, w);
         median25_pair(w, m0, m1);
         float g0 = s_g[oy + 2][ox + 2], g1 = s_g[oy + 2][ox + 3];
-        float r0 = m0 + g0, r1 = m1 + g1;
+        r0 = m0 + g0; r1 = m1 + g1;
         load_pair_window(&s_dbg[0][0], B4X, oy, ox, w);
         median25_pair(w, m0, m1);
-        float b0 = m0 + g0, b1 = m1 + g1;
-        *reinterpret_cast<float2*>(&s_r1[oy][ox]) = make_float2(r0, r1);
-        *reinterpret_cast<float2*>(&s_b1[oy][ox]) = make_float2(b0, b1);
+        b0 = m0 + g0; b1 = m1 + g1;
         *reinterpret_cast<float2*>(&s_d1[oy][ox]) = make_float2(g0 - r0, g1 - r1);
         *reinterpret_cast<float2*>(&s_d2[oy][ox]) = make_float2(g0 - b0, g1 - b1);
+    };
+    constexpr int NPAIR_IN = BTY * (BTX / 2), NCEN = NPAIR_IN / NT_B;
+    static_assert(NPAIR_IN % NT_B == 0, "every thread owns the same number of interior pixel pairs");
+    float keep[NCEN][4];                                            // r'0, r'1, b'0, b'1 of this thread's interior pairs
+#pragma unroll
+    for (int k = 0; k < NCEN; k++) {
+        int idx = tid + k * NT_B;
+        int ly = idx / (BTX / 2), lx = 2 * (idx - ly * (BTX / 2));
+        keep[k][0] = keep[k][1] = keep[k][2] = keep[k][3] = 0.0f;
+        if (ty0 + ly < H && tx0 + lx < W) first_level(ly + 2, lx + 2, keep[k][0], keep[k][1], keep[k][2], keep[k][3]);
+    }
+    {   // ring of the halo-2 region: rows 0,1 and B2Y-2,B2Y-1 in full, the two outer pairs of every other row
+        constexpr int NTB = 4 * (B2X / 2), NRING = NTB + 2 * BTY;
+        for (int t = tid; t < NRING; t += NT_B) {
+            int oy, ox;
+            if (t < NTB) { int r = t / (B2X / 2); oy = r < 2 ? r : B2Y - 4 + r; ox = 2 * (t - r * (B2X / 2)); }
+            else { int u = t - NTB; oy = 2 + (u >> 1); ox = (u & 1) ? B2X - 2 : 0; }
+            int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
+            if (y < 0 || y >= H || x < 0 || x >= W) continue;       // filled from the clamped position below
+            float r0, r1, b0, b1;
+            first_level(oy, ox, r0, r1, b0, b1);
+        }
     }
     __syncthreads();
     // medianBlur replicates the border of ITS input plane: a position outside the image takes the values of
@@ -475,7 +493,10 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < BTY * (BTX / 2); idx += NT_B) {
+    // Second level: g' = (med5(g-r') + med5(g-b') + r' + b') / 2, colour tail, store
+#pragma unroll
+    for (int k = 0; k < NCEN; k++) {
+        int idx = tid + k * NT_B;
         int ly = idx / (BTX / 2), lx = 2 * (idx - ly * (BTX / 2));
         int y = ty0 + ly, x = tx0 + lx;
         if (y >= H || x >= W) continue;
@@ -484,9 +505,7 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         median25_pair(w, ma0, ma1);
         load_pair_window(&s_d2[0][0], B2X, ly, lx, w);
         median25_pair(w, mb0, mb1);
-        float2 rr = *reinterpret_cast<const float2*>(&s_r1[ly + 2][lx + 2]);
-        float2 bb = *reinterpret_cast<const float2*>(&s_b1[ly + 2][lx + 2]);
-        float r0 = rr.x, b0 = bb.x, r1 = rr.y, b1 = bb.y;
+        float r0 = keep[k][0], r1 = keep[k][1], b0 = keep[k][2], b1 = keep[k][3];
         float g0 = (((ma0 + mb0) + r0) + b0) / 2.0f, g1 = (((ma1 + mb1) + r1) + b1) / 2.0f;
         colour_tail(p.tail, p.ccm.m, r0, g0, b0);
         colour_tail(p.tail, p.ccm.m, r1, g1, b1);
