@@ -9,12 +9,14 @@
 //   P1  green at red/blue sites, horizontal and vertical, and the colour differences D = sub - g
 //       (halo 2 quads; positions outside the image hold the REFLECT_101 value the 3x3 plane
 //       filters of resample_channel expect)
-//   then, for the horizontal and the vertical candidate in turn (one code path, looped):
+//   then, for the horizontal and the vertical candidate in turn (one code path, unrolled twice):
 //   P2  one thread per quad (halo 1 quad): high-pass of green, photosite-aware resampling of
 //       R and B, second white balance + float64 CCM + Lab, all in registers; Lab -> LDS
-//   P3  homogeneity vote from a 4x4 Lab window per quad (8-byte LDS reads, edge cells by select)
+//   P3  homogeneity vote from a 4x4 Lab window per quad (8-byte LDS reads, edge cells by select);
+//       the Lab buffer lies over the by then dead mosaic and horizontal g/D planes
 //   finally
-//   P4  3x3 box of the packed votes (integer), H/V selection, optional colour tail, store.
+//   P4  3x3 box of the packed votes (integer), H/V selection (both candidates still in registers), optional colour tail, store.
+// 92 VGPRs and 30.6 KB of LDS: five workgroups per CU.
 // Image-border rules (three of them coexist) are applied at true image edges only.
 #include "demosaic_common.h"
 #include "kernels.h"
@@ -22,18 +24,18 @@
 namespace {
 
 #ifndef AHD_TQX
-#define AHD_TQX 14                                // measured on MI355X: 256-thread workgroups (3 per CU at ~165 VGPRs)
-#define AHD_TQY 14                                // beat 384/512/640-thread ones by 1.3-1.9x despite the larger halo share
+#define AHD_TQX 14                                // measured on MI355X: 256-thread workgroups beat 384/512/640-thread ones
+#define AHD_TQY 14                                // by 1.3-1.9x despite the larger halo share
 #endif
 constexpr int TQX = AHD_TQX, TQY = AHD_TQY;       // output quads per tile; the 1-quad halo makes (TQX+2)x(TQY+2) threads
 constexpr int MWX = TQX + 6, MWY = TQY + 6;       // mosaic planes, halo 3 quads
 constexpr int GX = TQX + 4, GY = TQY + 4;         // green / difference planes, halo 2 quads
 constexpr int LQX = TQX + 2, LQY = TQY + 2;       // Lab region in quads (halo 1 quad = 2 px)
-constexpr int LPS = 2 * LQX + 2, LPR = 2 * LQY + 2;  // Lab plane stride / rows: region + 1 px guard ring (70 x 38)
-constexpr int MPS = 2 * TQX + 4, MPR = 2 * TQY + 2;  // packed vote map (halo 1 px), stride 68 (8-byte aligned rows)
-constexpr int NT_A = LQX * LQY;                    // 512: one thread per quad of the halo-1 region
+constexpr int LPS = 2 * LQX + 2, LPR = 2 * LQY + 2;  // Lab plane stride / rows: region + 1 px guard ring (34 x 34)
+constexpr int MPS = 2 * TQX + 4, MPR = 2 * TQY + 2;  // packed vote map (halo 1 px), stride 32 (8-byte aligned rows)
+constexpr int NT_A = LQX * LQY;                    // 256: one thread per quad of the halo-1 region
 #ifndef AHD_MIN_WAVES
-#define AHD_MIN_WAVES 1                           // measured: forcing 5 waves/SIMD (96 VGPRs) spills 51 dwords and is 45 % slower
+#define AHD_MIN_WAVES 1                           // the allocator reaches 92 VGPRs unforced; forcing a bound on earlier versions only spilled
 #endif
 
 constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // ahd.py:89-94
