@@ -52,9 +52,10 @@ def main() -> None:
     ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams (contexts) the frames of a rank are cycled over: consecutive frames are independent, so the "
-                         "next frame's first kernel fills the drain of the previous frame's last one")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams (contexts) the frames of a rank are cycled over.  With 2, consecutive (independent) frames overlap: the next "
+                         "frame's first kernel fills the drain of the previous frame's last one, +2 % throughput, but concurrent kernels "
+                         "stretch each other, so per-kernel durations (rocprofv3's, too) stop meaning anything; the default keeps them clean")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
