@@ -36,7 +36,10 @@ counts = {}
 while time.time() < t_end:
     seed = seed0 + n
     rng = np.random.default_rng(seed)
-    H, W = 2 * int(rng.integers(1, 120)), 2 * int(rng.integers(1, 160))
+    if rng.random() < 0.02:                                   # now and then a frame of many tiles
+        H, W = 2 * int(rng.integers(150, 400)), 2 * int(rng.integers(200, 520))
+    else:
+        H, W = 2 * int(rng.integers(1, 120)), 2 * int(rng.integers(1, 160))
     bay = frame(rng, H, W)
     wb = (1.0 / rng.uniform(0.3, 1.0, 3)).astype(np.float32)
     M = M0 * rng.uniform(0.8, 1.2, (3, 3)) if rng.random() < 0.5 else M0
