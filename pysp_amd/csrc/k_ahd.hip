@@ -390,6 +390,12 @@ DEVI void median25_pair(const float w[5][6], float& ml, float& mr) {
 #undef S3
     ml = v[12]; mr = u[12];
 }
+// The medians of four horizontally adjacent pixels from one 5x8 window: sorted columns, pairwise merges shared by the
+// windows, only the ranks a fifth column can still turn into the median (tools/gen_median_run4.py builds the network and
+// verifies every window on all 2^25 binary inputs): 72 operations per median against 98 for the pairwise network.
+DEVI void median25_run4(const float w[5][8], float& m0, float& m1, float& m2, float& m3) {
+#include "median25_run4.inc"
+}
 #undef CE1
 #undef S31
 }  // namespace
@@ -410,6 +416,15 @@ DEVI void load_pair_window(const float* plane, int stride, int ly, int lx, float
         const float2* row = reinterpret_cast<const float2*>(plane + (ly + dy) * stride + lx);
         float2 a = row[0], b = row[1], c = row[2];
         w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = c.x; w[dy][5] = c.y;
+    }
+}
+// Window of four horizontally adjacent pixels: 5 rows x 8 columns starting at an even column -> four 8-byte LDS reads per row.
+DEVI void load_run4_window(const float* plane, int stride, int ly, int lx, float w[5][8]) {
+#pragma unroll
+    for (int dy = 0; dy < 5; dy++) {
+        const float2* p = reinterpret_cast<const float2*>(plane + (ly + dy) * stride + lx);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { float2 v = p[q]; w[dy][2 * q] = v.x; w[dy][2 * q + 1] = v.y; }
     }
 }
 
@@ -443,31 +458,54 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
         }
     }
     __syncthreads();
-    // First level: r' = med5(r-g)+g, b' = med5(b-g)+g and the second-level differences g-r', g-b' on the halo-2 region, two
-    // horizontally adjacent pixels per thread (W and the tile origin are even, so a pair is inside or outside the image as a
-    // whole).  A thread takes the same pairs of the tile's interior here as at the second level below, so their r', b' stay in
-    // registers (only the differences go to LDS); the halo-2 ring is shared out afterwards.
-    auto first_level = [&](int oy, int ox, float& r0, float& r1, float& b0, float& b1) {   // (oy, ox): pair position in the halo-2 region
+    // First level: r' = med5(r-g)+g, b' = med5(b-g)+g and the second-level differences g-r', g-b' on the halo-2 region.
+    // W and the tile origin are even, so a pixel pair is inside or outside the image as a whole.  The tile's interior is done
+    // in runs of four pixels (median25_run4), one run per thread, the same run at both levels, so r', b' of the interior stay in
+    // registers and only the differences go to LDS; the halo-2 ring is shared out afterwards, in pixel pairs.
+    auto first_level_pair = [&](int oy, int ox) {   // (oy, ox): pair position in the halo-2 region
         float w[5][6], m0, m1;
         load_pair_window(&s_drg[0][0], B4X, oy, ox, w);
         median25_pair(w, m0, m1);
         float g0 = s_g[oy + 2][ox + 2], g1 = s_g[oy + 2][ox + 3];
-        r0 = m0 + g0; r1 = m1 + g1;
+        float r0 = m0 + g0, r1 = m1 + g1;
         load_pair_window(&s_dbg[0][0], B4X, oy, ox, w);
         median25_pair(w, m0, m1);
-        b0 = m0 + g0; b1 = m1 + g1;
+        float b0 = m0 + g0, b1 = m1 + g1;
         *reinterpret_cast<float2*>(&s_d1[oy][ox]) = make_float2(g0 - r0, g1 - r1);
         *reinterpret_cast<float2*>(&s_d2[oy][ox]) = make_float2(g0 - b0, g1 - b1);
     };
-    constexpr int NPAIR_IN = BTY * (BTX / 2), NCEN = NPAIR_IN / NT_B;
-    static_assert(NPAIR_IN % NT_B == 0, "every thread owns the same number of interior pixel pairs");
-    float keep[NCEN][4];                                            // r'0, r'1, b'0, b'1 of this thread's interior pairs
+    constexpr int RUNS_X = BTX / 4, NRUN = BTY * RUNS_X, NCEN = NRUN / NT_B;
+    static_assert(BTX % 4 == 0 && NRUN % NT_B == 0, "every thread owns the same number of interior four-pixel runs");
+    float keep_r[NCEN][4], keep_b[NCEN][4];                         // r', b' of this thread's interior pixels
 #pragma unroll
     for (int k = 0; k < NCEN; k++) {
-        int idx = tid + k * NT_B;
-        int ly = idx / (BTX / 2), lx = 2 * (idx - ly * (BTX / 2));
-        keep[k][0] = keep[k][1] = keep[k][2] = keep[k][3] = 0.0f;
-        if (ty0 + ly < H && tx0 + lx < W) first_level(ly + 2, lx + 2, keep[k][0], keep[k][1], keep[k][2], keep[k][3]);
+        const int idx = tid + k * NT_B;
+        const int ly = idx / RUNS_X, lx = 4 * (idx - ly * RUNS_X);
+        const int oy = ly + 2, ox = lx + 2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) keep_r[k][q] = keep_b[k][q] = 0.0f;
+        if (ty0 + ly < H && tx0 + lx < W) {
+            float w[5][8], m[4];
+            const float4 g4 = make_float4(s_g[oy + 2][ox + 2], s_g[oy + 2][ox + 3], s_g[oy + 2][ox + 4], s_g[oy + 2][ox + 5]);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+            load_run4_window(&s_drg[0][0], B4X, oy, ox, w);
+            median25_run4(w, m[0], m[1], m[2], m[3]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) keep_r[k][q] = m[q] + gg[q];
+            load_run4_window(&s_dbg[0][0], B4X, oy, ox, w);
+            median25_run4(w, m[0], m[1], m[2], m[3]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) keep_b[k][q] = m[q] + gg[q];
+            // the second pair of the run may lie beyond the right image border (W = 2 mod 4): its cells are then filled by the
+            // border pass below like every other outside position
+            const bool second = tx0 + lx + 2 < W;
+            *reinterpret_cast<float2*>(&s_d1[oy][ox]) = make_float2(gg[0] - keep_r[k][0], gg[1] - keep_r[k][1]);
+            *reinterpret_cast<float2*>(&s_d2[oy][ox]) = make_float2(gg[0] - keep_b[k][0], gg[1] - keep_b[k][1]);
+            if (second) {
+                *reinterpret_cast<float2*>(&s_d1[oy][ox + 2]) = make_float2(gg[2] - keep_r[k][2], gg[3] - keep_r[k][3]);
+                *reinterpret_cast<float2*>(&s_d2[oy][ox + 2]) = make_float2(gg[2] - keep_b[k][2], gg[3] - keep_b[k][3]);
+            }
+        }
     }
     {   // ring of the halo-2 region: rows 0,1 and B2Y-2,B2Y-1 in full, the two outer pairs of every other row
         constexpr int NTB = 4 * (B2X / 2), NRING = NTB + 2 * BTY;
@@ -477,8 +515,7 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
             else { int u = t - NTB; oy = 2 + (u >> 1); ox = (u & 1) ? B2X - 2 : 0; }
             int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
             if (y < 0 || y >= H || x < 0 || x >= W) continue;       // filled from the clamped position below
-            float r0, r1, b0, b1;
-            first_level(oy, ox, r0, r1, b0, b1);
+            first_level_pair(oy, ox);
         }
     }
     __syncthreads();
@@ -498,24 +535,33 @@ __global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
     // Second level: g' = (med5(g-r') + med5(g-b') + r' + b') / 2, colour tail, store
 #pragma unroll
     for (int k = 0; k < NCEN; k++) {
-        int idx = tid + k * NT_B;
-        int ly = idx / (BTX / 2), lx = 2 * (idx - ly * (BTX / 2));
-        int y = ty0 + ly, x = tx0 + lx;
+        const int idx = tid + k * NT_B;
+        const int ly = idx / RUNS_X, lx = 4 * (idx - ly * RUNS_X);
+        const int y = ty0 + ly, x = tx0 + lx;
         if (y >= H || x >= W) continue;
-        float w[5][6], ma0, ma1, mb0, mb1;
-        load_pair_window(&s_d1[0][0], B2X, ly, lx, w);
-        median25_pair(w, ma0, ma1);
-        load_pair_window(&s_d2[0][0], B2X, ly, lx, w);
-        median25_pair(w, mb0, mb1);
-        float r0 = keep[k][0], r1 = keep[k][1], b0 = keep[k][2], b1 = keep[k][3];
-        float g0 = (((ma0 + mb0) + r0) + b0) / 2.0f, g1 = (((ma1 + mb1) + r1) + b1) / 2.0f;
-        colour_tail(p.tail, p.ccm.m, r0, g0, b0);
-        colour_tail(p.tail, p.ccm.m, r1, g1, b1);
-        float* o = p.out + ((size_t)y * W + x) * 3;
-        // six contiguous floats, 8-byte aligned (x is even)
-        reinterpret_cast<float2*>(o)[0] = make_float2(r0, g0);
-        reinterpret_cast<float2*>(o)[1] = make_float2(b0, r1);
-        reinterpret_cast<float2*>(o)[2] = make_float2(g1, b1);
+        float w[5][8], ma[4], mb[4];
+        load_run4_window(&s_d1[0][0], B2X, ly, lx, w);
+        median25_run4(w, ma[0], ma[1], ma[2], ma[3]);
+        load_run4_window(&s_d2[0][0], B2X, ly, lx, w);
+        median25_run4(w, mb[0], mb[1], mb[2], mb[3]);
+        float o[12];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float r = keep_r[k][q], b = keep_b[k][q];
+            float g = (((ma[q] + mb[q]) + r) + b) / 2.0f;
+            colour_tail(p.tail, p.ccm.m, r, g, b);
+            o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
+        }
+        float* dst = p.out + ((size_t)y * W + x) * 3;
+        // two pixels = six contiguous floats, 8-byte aligned (x is even); the second pair only if it is inside the image
+        reinterpret_cast<float2*>(dst)[0] = make_float2(o[0], o[1]);
+        reinterpret_cast<float2*>(dst)[1] = make_float2(o[2], o[3]);
+        reinterpret_cast<float2*>(dst)[2] = make_float2(o[4], o[5]);
+        if (x + 2 < W) {
+            reinterpret_cast<float2*>(dst)[3] = make_float2(o[6], o[7]);
+            reinterpret_cast<float2*>(dst)[4] = make_float2(o[8], o[9]);
+            reinterpret_cast<float2*>(dst)[5] = make_float2(o[10], o[11]);
+        }
     }
 }
 
