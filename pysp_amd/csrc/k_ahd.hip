@@ -428,7 +428,11 @@ DEVI void load_run4_window(const float* plane, int stride, int ly, int lx, float
     }
 }
 
-__global__ void __launch_bounds__(NT_B) k_ahd_median_stage(MedParams p) {
+#ifndef MED_MIN_WAVES
+#define MED_MIN_WAVES 1                            // 104 VGPRs, 4 waves/SIMD.  Forcing 5 (96 VGPRs, 5 spilled to scratch) measured 2 % faster,
+                                                  // but the two-process band test then failed: no kernel of this library uses scratch
+#endif
+__global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedParams p) {
     __shared__ __attribute__((aligned(16))) float s_g[B4Y][B4X], s_drg[B4Y][B4X], s_dbg[B4Y][B4X];   // g, r-g, b-g (halo 4)
     __shared__ __attribute__((aligned(16))) float s_d1[B2Y][B2X], s_d2[B2Y][B2X];                     // g-r', g-b'  (halo 2)
     const int tid = threadIdx.x, H = p.H, W = p.W;
