@@ -513,8 +513,8 @@ __global__ void __launch_bounds__(256) k_ca_remap_sites(const float* __restrict_
 // inverse model's coordinates) straight into an LDS tile, and resample_r / resample_b (eag.py:160-186 -> :126-143) runs on that tile:
 // the remapped green never goes to memory.  One workgroup = 32x8 CFA quads (64x16 px), one thread per quad; the tile carries a
 // 2 px ring (1 quad for the 3x3 quarter-plane filters, 1 px for the 3x3 blur).  Quads on the image border need two different
-// reflections of that ring (REFLECT_101 of the quarter plane for filter2D, of the full plane for GaussianBlur): they evaluate
-// their windows directly instead of reading the tile -- a perimeter's worth of extra remaps.
+// reflections of that ring (REFLECT_101 of the quarter plane for filter2D, of the full plane for GaussianBlur): a second, tiny
+// kernel evaluates their windows directly (k_ca_upsample_border, one thread per border quad).
 namespace {
 constexpr int CUX = 32, CUY = 8;                       // quads per workgroup
 constexpr int CTW = 2 * CUX + 4, CTH = 2 * CUY + 4;    // green tile in px: 68 x 20
@@ -529,11 +529,6 @@ __global__ void __launch_bounds__(256) k_ca_upsample_fused(const float* __restri
     xcd_tile(tbx, tby);
     const int tid = threadIdx.x, q0x = tbx * CUX, q0y = tby * CUY;
     const int H = g.H, W = g.W, h = g.h, w = g.w;
-    auto gat = [&](int Y, int X) {                      // remapped green at an in-image pixel
-        float mx, my;
-        ca_map(quad, g, Y, X, mx, my);
-        return remap_linear_px(g_full, H, W, mx, my);
-    };
     {   // tile of remapped green in three sweeps over a thread's cells, so that every sweep's loads are in flight together:
         // coordinate field, then the four taps, then the blend (remap_linear_px split in two)
         constexpr int NC = (CTH * CTW + 255) / 256;
@@ -590,7 +585,8 @@ __global__ void __launch_bounds__(256) k_ca_upsample_fused(const float* __restri
     if (i >= h || j >= w) return;
     Win3 wg, wd;
     float Wn[4][4];
-    if (i >= 1 && i <= h - 2 && j >= 1 && j <= w - 2) {
+    if (!(i >= 1 && i <= h - 2 && j >= 1 && j <= w - 2)) return;   // border quads: k_ca_upsample_border
+    {
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -603,21 +599,41 @@ __global__ void __launch_bounds__(256) k_ca_upsample_fused(const float* __restri
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int c = 0; c < 4; c++) Wn[r][c] = s_gat[2 * lqy + 1 + r][2 * lqx + 1 + c];
-    } else {
-#pragma unroll 1
-        for (int r = 0; r < 3; r++)
-#pragma unroll 1
-            for (int c = 0; c < 3; c++) {                                      // REFLECT_101 of the quarter planes
-                int a = b_101(i - 1 + r, h), cc = b_101(j - 1 + c, w);
-                float gs = gat(2 * a + O, 2 * cc + O);
-                wg.v[r][c] = gs;
-                wd.v[r][c] = bayer[(size_t)(2 * a + O) * W + 2 * cc + O] * wb - gs;
-            }
-#pragma unroll 1
-        for (int r = 0; r < 4; r++)
-#pragma unroll 1
-            for (int c = 0; c < 4; c++) Wn[r][c] = gat(b_101(2 * i - 1 + r, H), b_101(2 * j - 1 + c, W));   // REFLECT_101 at full resolution
     }
+    float hf[4], fg[4], fd[4];
+    highpass_quad(Wn, hf);
+    if (O == 0) { filt_base_tl(wg, fg); filt_base_tl(wd, fd); } else { filt_base_br(wg, fg); filt_base_br(wd, fd); }
+    *reinterpret_cast<float2*>(out + (size_t)(2 * i) * W + 2 * j) = make_float2(fd[0] + (fg[0] + hf[0]), fd[1] + (fg[1] + hf[1]));
+    *reinterpret_cast<float2*>(out + (size_t)(2 * i + 1) * W + 2 * j) = make_float2(fd[2] + (fg[2] + hf[2]), fd[3] + (fg[3] + hf[3]));
+}
+template <int O>
+__global__ void __launch_bounds__(64) k_ca_upsample_border(const float* __restrict__ bayer, const float* __restrict__ g_full, CaGeom g,
+                                                          const float* __restrict__ quad, float wb, float* __restrict__ out) {
+    const int H = g.H, W = g.W, h = g.h, w = g.w;
+    int t = blockIdx.x * 64 + threadIdx.x, i, j;
+    if (t < w) { i = 0; j = t; }
+    else if (t < 2 * w) { i = h - 1; j = t - w; }
+    else { int u = t - 2 * w; i = 1 + (u >> 1); j = (u & 1) ? w - 1 : 0; if (i > h - 2) return; }
+    auto gat = [&](int Y, int X) {
+        float mx, my;
+        ca_map(quad, g, Y, X, mx, my);
+        return remap_linear_px(g_full, H, W, mx, my);
+    };
+    Win3 wg, wd;
+    float Wn[4][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {                                      // REFLECT_101 of the quarter planes
+            int a = b_101(i - 1 + r, h), cc = b_101(j - 1 + c, w);
+            float gs = gat(2 * a + O, 2 * cc + O);
+            wg.v[r][c] = gs;
+            wd.v[r][c] = bayer[(size_t)(2 * a + O) * W + 2 * cc + O] * wb - gs;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) Wn[r][c] = gat(b_101(2 * i - 1 + r, H), b_101(2 * j - 1 + c, W));   // REFLECT_101 at full resolution
     float hf[4], fg[4], fd[4];
     highpass_quad(Wn, hf);
     if (O == 0) { filt_base_tl(wg, fg); filt_base_tl(wd, fd); } else { filt_base_br(wg, fg); filt_base_br(wd, fd); }
@@ -626,9 +642,17 @@ __global__ void __launch_bounds__(256) k_ca_upsample_fused(const float* __restri
 }
 int launch_ca_upsample_fused(hipStream_t st, const float* bayer, const float* g_full, int H, int W, const float* d_quad, int pos, float wb, float* out) {
     if (pos != 0 && pos != 3) return -1;
-    dim3 grid((W / 2 + CUX - 1) / CUX, (H / 2 + CUY - 1) / CUY);
-    if (pos == 0) hipLaunchKernelGGL(k_ca_upsample_fused<0>, grid, dim3(256), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
-    else hipLaunchKernelGGL(k_ca_upsample_fused<1>, grid, dim3(256), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
+    const int h = H / 2, w = W / 2;
+    dim3 grid((w + CUX - 1) / CUX, (h + CUY - 1) / CUY);
+    const int nborder = 2 * w + 2 * (h > 2 ? h - 2 : 0);
+    dim3 gb((nborder + 63) / 64);
+    if (pos == 0) {
+        hipLaunchKernelGGL(k_ca_upsample_fused<0>, grid, dim3(256), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
+        hipLaunchKernelGGL(k_ca_upsample_border<0>, gb, dim3(64), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
+    } else {
+        hipLaunchKernelGGL(k_ca_upsample_fused<1>, grid, dim3(256), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
+        hipLaunchKernelGGL(k_ca_upsample_border<1>, gb, dim3(64), 0, st, bayer, g_full, ca_geom(H, W), d_quad, wb, out);
+    }
     return CHECK_LAUNCH();
 }
 int launch_ca_remap_sites(hipStream_t st, const float* src, int H, int W, const float* d_quad, int oy, int ox, float wb, float* bayer) {
