@@ -160,3 +160,35 @@ def test_reference_import_paths_exist():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+def test_no_kernel_uses_scratch_or_spills(tmp_path):
+    """Every gfx950 kernel in the built library keeps its state in registers/LDS: no private (scratch) segment, no spilled VGPRs.
+    (A spilled variant of the median stage was 2 % faster and failed the two-process band test; dynamically indexed register
+    arrays once put the CA kernel's border path in scratch and cost it 40 %.)"""
+    import shutil
+    import subprocess
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-objdump")):
+        pytest.skip("ROCm LLVM tools not available")
+    lib = shutil.copy(os.path.join(ROOT, "pysp_amd", "csrc", "libpysp_hip.so"), tmp_path)
+    subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], cwd=tmp_path, check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, "no gfx950 code objects found in the library"
+    kernels = {}
+    for f in objs:
+        notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", os.path.join(tmp_path, f)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+                kernels[name] = {}
+            elif name and line.startswith((".private_segment_fixed_size:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".vgpr_count:")):
+                k, v = line.split(":")
+                kernels[name][k.strip(".")] = int(v)
+    assert len(kernels) >= 30
+    bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
+    sel = [v for k, v in kernels.items() if "k_ahd_select" in k]
+    assert sel and all(v["vgpr_count"] <= 96 for v in sel)          # five workgroups per CU need <= 96 VGPRs (and <= 32 KB of LDS)
