@@ -486,8 +486,6 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
         const int idx = tid + k * NT_B;
         const int ly = idx / RUNS_X, lx = 4 * (idx - ly * RUNS_X);
         const int oy = ly + 2, ox = lx + 2;
-#pragma unroll
-        for (int q = 0; q < 4; q++) keep_r[k][q] = keep_b[k][q] = 0.0f;
         if (ty0 + ly < H && tx0 + lx < W) {
             float w[5][8], m[4];
             const float4 g4 = make_float4(s_g[oy + 2][ox + 2], s_g[oy + 2][ox + 3], s_g[oy + 2][ox + 4], s_g[oy + 2][ox + 5]);
@@ -548,23 +546,16 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
         median25_run4(w, ma[0], ma[1], ma[2], ma[3]);
         load_run4_window(&s_d2[0][0], B2X, ly, lx, w);
         median25_run4(w, mb[0], mb[1], mb[2], mb[3]);
-        float o[12];
+        float gq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) gq[q] = (((ma[q] + mb[q]) + keep_r[k][q]) + keep_b[k][q]) / 2.0f;
+        float* dst = p.out + ((size_t)y * W + x) * 3;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            float r = keep_r[k][q], b = keep_b[k][q];
-            float g = (((ma[q] + mb[q]) + r) + b) / 2.0f;
+            if (q >= 2 && x + 2 >= W) break;         // the second pair only if it is inside the image
+            float r = keep_r[k][q], g = gq[q], b = keep_b[k][q];
             colour_tail(p.tail, p.ccm.m, r, g, b);
-            o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
-        }
-        float* dst = p.out + ((size_t)y * W + x) * 3;
-        // two pixels = six contiguous floats, 8-byte aligned (x is even); the second pair only if it is inside the image
-        reinterpret_cast<float2*>(dst)[0] = make_float2(o[0], o[1]);
-        reinterpret_cast<float2*>(dst)[1] = make_float2(o[2], o[3]);
-        reinterpret_cast<float2*>(dst)[2] = make_float2(o[4], o[5]);
-        if (x + 2 < W) {
-            reinterpret_cast<float2*>(dst)[3] = make_float2(o[6], o[7]);
-            reinterpret_cast<float2*>(dst)[4] = make_float2(o[8], o[9]);
-            reinterpret_cast<float2*>(dst)[5] = make_float2(o[10], o[11]);
+            dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b;   // one pixel at a time: the float64 tails of four pixels do not pile up in registers
         }
     }
 }
