@@ -34,6 +34,7 @@ KERNEL_ALG_BYTES_PER_PX = {"k_ahd_select": 16, "k_ahd_median_stage": 24}
 WORKLOADS = {
     # name: (H, W, quality, stages, description[, tail])   tail: 2 = to_lin_srgb + lin_srgb_to_srgb (default), 1 = to_lin_srgb only
     "ahd24": (4000, 6000, 2, 1, "24MP RGGB, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb"),
+    "ahd24u16": (4000, 6000, 2, 1, "24MP RGGB uint16 sensor mosaic, bayer_normalize fused into the tile loader + AHD (postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb (14 B/px)"),
     "eag24": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + to_lin_srgb + lin_srgb_to_srgb"),
     "draft12": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + to_lin_srgb + lin_srgb_to_srgb"),
     "eag24ccm": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + WB + 3x3 CCM (to_lin_srgb), BASELINE config 3 per frame", 1),
@@ -113,11 +114,24 @@ def main() -> None:
         frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
         outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(n_streams)]
 
-        def step(i: int) -> None:
-            f = frames[i % len(frames)]
-            s = i % n_streams                       # frame i runs on stream s, writing that stream's output buffer
-            _lib.check(L.pysp_pipeline_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, tail,
-                                           ctypes.c_void_p(outs[s].data_ptr())))
+        if args.workload.endswith("u16"):
+            # 14-bit sensor counts, black 512, saturation 15871 per site (normalization.py:4-24 runs inside the tile loaders)
+            frames = [(f * 15359.0 + 512.0).round().clamp(0, 16383).to(torch.int32).to(torch.int16).view(torch.uint16).contiguous() for f in frames]
+            black = (ctypes.c_float * 4)(512.0, 512.0, 512.0, 512.0)
+            sat = (ctypes.c_float * 4)(15871.0, 15871.0, 15871.0, 15871.0)
+            alg_bytes_per_px = 14
+
+            def step(i: int) -> None:
+                f = frames[i % len(frames)]
+                s = i % n_streams
+                _lib.check(L.pysp_pipeline_u16_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, black, sat, wb, M, quality, 0, stages, tail,
+                                                   ctypes.c_void_p(outs[s].data_ptr())))
+        else:
+            def step(i: int) -> None:
+                f = frames[i % len(frames)]
+                s = i % n_streams                       # frame i runs on stream s, writing that stream's output buffer
+                _lib.check(L.pysp_pipeline_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, tail,
+                                               ctypes.c_void_p(outs[s].data_ptr())))
     elif quality == -1:
         K = 7
         base = rggb_frame(H, W, 1000 + rank, scale=8.0, clip_hi=False)
