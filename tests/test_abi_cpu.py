@@ -184,11 +184,13 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
             if line.startswith(".name:"):
                 name = line.split(":", 1)[1].strip()
                 kernels[name] = {}
-            elif name and line.startswith((".private_segment_fixed_size:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".vgpr_count:")):
+            elif name and line.startswith((".private_segment_fixed_size:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".vgpr_count:", ".group_segment_fixed_size:")):
                 k, v = line.split(":")
                 kernels[name][k.strip(".")] = int(v)
     assert len(kernels) >= 30
     bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
-    sel = [v for k, v in kernels.items() if "k_ahd_select" in k]
-    assert sel and all(v["vgpr_count"] <= 96 for v in sel)          # five workgroups per CU need <= 96 VGPRs (and <= 32 KB of LDS)
+    hot = [v for k, v in kernels.items() if "k_ahd_select" in k or "k_ahd_median_stage" in k]
+    assert len(hot) == 5                                             # four select variants (tiny / uint16) and the median stage
+    for v in hot:                                                    # five 256-thread workgroups per CU: <= 96 VGPRs and <= 32 KB of LDS each
+        assert v["vgpr_count"] <= 96 and v["group_segment_fixed_size"] <= 32768, v
