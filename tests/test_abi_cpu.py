@@ -178,15 +178,19 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
     kernels = {}
     for f in objs:
         notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", os.path.join(tmp_path, f)], check=True, capture_output=True, text=True).stdout
-        name = None
+        cur = None
         for line in notes.splitlines():
             line = line.strip()
+            if line.startswith("- ."):                      # a new kernel's metadata map begins (keys come in alphabetical order)
+                cur = {}
+                line = line[2:]
+            if cur is None:
+                continue
             if line.startswith(".name:"):
-                name = line.split(":", 1)[1].strip()
-                kernels[name] = {}
-            elif name and line.startswith((".private_segment_fixed_size:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".vgpr_count:", ".group_segment_fixed_size:")):
+                kernels[line.split(":", 1)[1].strip()] = cur
+            elif line.startswith((".private_segment_fixed_size:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".vgpr_count:", ".group_segment_fixed_size:")):
                 k, v = line.split(":")
-                kernels[name][k.strip(".")] = int(v)
+                cur[k.strip(".")] = int(v)
     assert len(kernels) >= 30
     bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
