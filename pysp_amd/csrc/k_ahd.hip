@@ -152,6 +152,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     xcd_tile(tbx, tby);
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const double* M = p.ccm.m;
+    // the whole halo-3 neighbourhood of the tile lies inside the image: no border rule applies anywhere in P0/P1
+    const bool inside = tq0y >= 3 && tq0x >= 3 && tq0y + TQY + 3 <= h && tq0x + TQX + 3 <= w;
 
     // ---- P0: white-balanced mosaic planes, symmetric (edge-duplicating) reflect per plane (ahd.py:77-80).
     // One 8-byte load per quad row; a thread's loads are all issued before its first LDS store.
@@ -168,8 +170,11 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             int idx = tid + k * NT_A;
             if (idx >= NPAIR) idx = NPAIR - 1;
             int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
-            int qi = TINY ? b_sym(tq0y - 3 + my, h) : b_sym1(tq0y - 3 + my, h);
-            int qj = TINY ? b_sym(tq0x - 3 + mx, w) : b_sym1(tq0x - 3 + mx, w);
+            int qi = tq0y - 3 + my, qj = tq0x - 3 + mx;
+            if (!inside) {                                                     // uniform per workgroup: interior tiles skip the border rules
+                qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
+                qj = TINY ? b_sym(qj, w) : b_sym1(qj, w);
+            }
             tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
         }
 #pragma unroll
@@ -191,10 +196,13 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     // ---- P1: directional green at R/B sites (ahd.py:97-102) and D = sub - g (eag.py:142)
     for (int idx = tid; idx < GY * GX; idx += NT_A) {
         int gy = idx / GX, gx = idx - gy * GX;
-        int ri = TINY ? b_101(tq0y - 2 + gy, h) : b_1011(tq0y - 2 + gy, h);   // REFLECT_101 on the quarter plane
-        int rj = TINY ? b_101(tq0x - 2 + gx, w) : b_1011(tq0x - 2 + gx, w);
-        int a = ri - (tq0y - 3), c = rj - (tq0x - 3);
-        if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;        // never consumed by a valid output
+        int a = gy + 1, c = gx + 1;
+        if (!inside) {
+            int ri = TINY ? b_101(tq0y - 2 + gy, h) : b_1011(tq0y - 2 + gy, h);   // REFLECT_101 on the quarter plane
+            int rj = TINY ? b_101(tq0x - 2 + gx, w) : b_1011(tq0x - 2 + gx, w);
+            a = ri - (tq0y - 3); c = rj - (tq0x - 3);
+            if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;        // never consumed by a valid output
+        }
         float rc = MWAT(P_R, a, c), bc = MWAT(P_B, a, c);
         float ghr = (((MWAT(P_R, a, c - 1) * AH0 + MWAT(P_G1, a, c - 1) * AH1) + rc * AH2) + MWAT(P_G1, a, c) * AH1) + MWAT(P_R, a, c + 1) * AH0;
         float gvr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
@@ -442,13 +450,15 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
 
     {   // all global loads of a thread are issued before its first LDS store (they are in flight together)
         constexpr int NL = (B4Y * B4X + NT_B - 1) / NT_B;
+        const bool inside = ty0 >= 4 && tx0 >= 4 && ty0 + BTY + 4 <= H && tx0 + BTX + 4 <= W;
         float tr[NL], tg[NL], tb[NL];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             int idx = tid + k * NT_B;
             if (idx >= B4Y * B4X) idx = B4Y * B4X - 1;
             int ly = idx / B4X, lx = idx - ly * B4X;
-            int y = b_rep(ty0 - 4 + ly, H), x = b_rep(tx0 - 4 + lx, W);
+            int y = ty0 - 4 + ly, x = tx0 - 4 + lx;
+            if (!inside) { y = b_rep(y, H); x = b_rep(x, W); }       // uniform per workgroup: interior tiles skip the clamps
             const float* s = p.in + ((size_t)y * W + x) * 3;
             tr[k] = s[0]; tg[k] = s[1]; tb[k] = s[2];
         }
