@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
+    const bool inside = tq0y >= 2 && tq0x >= 2 && tq0y + TQY + 2 <= h && tq0x + TQX + 2 <= w;   // no border rule applies in P0/P1
 
     // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87).  One 8-byte load per quad
     // row; all loads of a thread are issued before the first LDS store so that they are in flight together.
@@ -62,8 +63,11 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
             int idx = tid + k * NT;
             if (idx >= NPAIR) idx = NPAIR - 1;
             int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
-            int qi = TINY ? b_sym(tq0y - 2 + my, h) : b_sym1(tq0y - 2 + my, h);
-            int qj = TINY ? b_sym(tq0x - 2 + mx, w) : b_sym1(tq0x - 2 + mx, w);
+            int qi = tq0y - 2 + my, qj = tq0x - 2 + mx;
+            if (!inside) {                                                     // uniform per workgroup: interior tiles skip the border rules
+                qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
+                qj = TINY ? b_sym(qj, w) : b_sym1(qj, w);
+            }
             tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
         }
 #pragma unroll
@@ -81,10 +85,13 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     // P1: green at red / blue sites (eag.py:99-121), * wb[1] (:193); D = sub*wb - g (:142,:194)
     for (int idx = tid; idx < GY * GX; idx += NT) {
         int gy = idx / GX, gx = idx - gy * GX;
-        int ri = TINY ? b_101(tq0y - 1 + gy, h) : b_1011(tq0y - 1 + gy, h);
-        int rj = TINY ? b_101(tq0x - 1 + gx, w) : b_1011(tq0x - 1 + gx, w);
-        int a = ri - (tq0y - 2), c = rj - (tq0x - 2);
-        if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;
+        int a = gy + 1, c = gx + 1;
+        if (!inside) {
+            int ri = TINY ? b_101(tq0y - 1 + gy, h) : b_1011(tq0y - 1 + gy, h);
+            int rj = TINY ? b_101(tq0x - 1 + gx, w) : b_1011(tq0x - 1 + gx, w);
+            a = ri - (tq0y - 2); c = rj - (tq0x - 2);
+            if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;
+        }
         float gr = delta_mix(mw[P_G2][a - 1][c], mw[P_G2][a][c], mw[P_G1][a][c - 1], mw[P_G1][a][c]) * p.wb[1];
         float gb = delta_mix(mw[P_G1][a][c], mw[P_G1][a + 1][c], mw[P_G2][a][c], mw[P_G2][a][c + 1]) * p.wb[1];
         gq[Q_GR][gy][gx] = gr; gq[Q_GB][gy][gx] = gb;
