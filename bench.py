@@ -230,7 +230,7 @@ def main() -> None:
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
                     "alg_bytes_per_px": KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px),
                     "pipeline_frac": round(alg_bytes_per_px * H * W / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "AHD is VALU-issue bound (753 + 551 wave-level instructions per pixel in the two kernels vs 16 B/px for the path, one every 3.0 / 3.4 cycles per SIMD, profiles/r1_v18_pmc_summary.csv); pipeline_frac is the whole two-kernel step against the path's 16 B/px; the HBM fraction is reported as required, not expected to approach 1"}
+                    "note": "AHD is VALU-issue bound (725 + 543 wave-level instructions per pixel in the two kernels vs 16 B/px for the path, one every 3.0 / 3.3 cycles per SIMD, profiles/r1_v19_pmc_summary.csv); pipeline_frac is the whole two-kernel step against the path's 16 B/px; the HBM fraction is reported as required, not expected to approach 1"}
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline and quality >= 0:
