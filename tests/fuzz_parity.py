@@ -1,4 +1,5 @@
-"""Randomised GPU-vs-oracle parity run (bit-exact): python tools/fuzz_parity.py [seconds] [seed]
+"""Randomised GPU-vs-oracle parity run (bit-exact): python tests/fuzz_parity.py [seconds] [seed]
+Test infrastructure (it calls the CPU oracle); a 10-second slice of it runs inside the GPU suite (test_gpu_parity.py::test_fuzz_slice).
 Random even frame sizes, value distributions (uniform, heavy-tailed, saturated, zeros, negatives, tiny), qualities, HDR flag,
 post-process stage counts, colour tails, uint16 input, CA removal, raw fusion.  Stops at the first mismatch with a reproducer line."""
 import os, sys, time

@@ -863,3 +863,13 @@ def test_signed_zero_bits_match_oracle(orc, wbobj):
     for q, ref in ((QualityDemosaic.Fast, orc.demosaic_eag(bay, wb)), (QualityDemosaic.Best, orc.demosaic_ahd(bay, wb, M, False, 1))):
         got = _raw(bay.copy(), wbobj).demosaic(q).image
         assert got.tobytes() == ref.tobytes(), q
+
+
+def test_fuzz_slice():
+    """Ten seconds of tests/fuzz_parity.py (random sizes, value distributions, qualities, tails, uint16, CA, fusion) inside the suite."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "fuzz_parity.py"), "10", "20260101"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bit-exact" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
