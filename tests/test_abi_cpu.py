@@ -50,12 +50,13 @@ def test_no_gpu_means_loud_failure():
 
 def test_product_never_imports_oracle():
     bad = []
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "pysp_amd")):
-        for f in files:
-            if f.endswith((".py", ".hip", ".cpp", ".h")):
-                txt = open(os.path.join(dirpath, f)).read()
-                if re.search(r"^\s*(from|import)\s+\.*oracle\b|liboracle|pysp_oracle\.c\"", txt, flags=re.M):
-                    bad.append(f)
+    for top in ("pysp_amd", "tools"):          # the product, and the measurement tools: only tests/, smoke() and bench's CPU baseline use the oracle
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+\.*oracle\b|liboracle|pysp_oracle\.c\"", txt, flags=re.M):
+                        bad.append(os.path.join(top, f))
     assert not bad, bad
 
 
