@@ -42,7 +42,8 @@ struct EagParams {
     Ccm ccm;
 };
 
-template <bool TINY, bool U16>
+// TAIL is a template parameter: with the colour tail chosen at run time the kernel needs 66 VGPRs, with it fixed 40 (8 waves/SIMD)
+template <bool TINY, bool U16, int TAIL>
 __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     __shared__ float mw[4][MWY][MWX];
     __shared__ float gq[4][GY][GX];
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         float r = rr[k], g = gg[k], b = bb[k];
-        colour_tail(p.tail, p.ccm.m, r, g, b);
+        colour_tail(TAIL, p.ccm.m, r, g, b);
         float* o = p.out + ((size_t)(2 * qi + (k >> 1)) * W + (2 * qj + (k & 1))) * 3;
         o[0] = r; o[1] = g; o[2] = b;
     }
@@ -153,10 +154,21 @@ int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
     dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_eag");
     const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
-    if (tiny && u16) hipLaunchKernelGGL((k_eag<true, true>), g, dim3(NT), 0, st, a);
-    else if (tiny) hipLaunchKernelGGL((k_eag<true, false>), g, dim3(NT), 0, st, a);
-    else if (u16) hipLaunchKernelGGL((k_eag<false, true>), g, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((k_eag<false, false>), g, dim3(NT), 0, st, a);
+#define EAG_LAUNCH(T) \
+    do { \
+        if (tiny && u16) hipLaunchKernelGGL((k_eag<true, true, T>), g, dim3(NT), 0, st, a); \
+        else if (tiny) hipLaunchKernelGGL((k_eag<true, false, T>), g, dim3(NT), 0, st, a); \
+        else if (u16) hipLaunchKernelGGL((k_eag<false, true, T>), g, dim3(NT), 0, st, a); \
+        else hipLaunchKernelGGL((k_eag<false, false, T>), g, dim3(NT), 0, st, a); \
+    } while (0)
+    switch (tail) {
+        case 0: EAG_LAUNCH(0); break;
+        case 1: EAG_LAUNCH(1); break;
+        case 2: EAG_LAUNCH(2); break;
+        case 3: EAG_LAUNCH(3); break;
+        default: return -1;
+    }
+#undef EAG_LAUNCH
     if (tl) tl->end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
