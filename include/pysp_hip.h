@@ -50,6 +50,13 @@ int pysp_device_count(void);
  * borrowed from the caller (e.g. torch.cuda.current_stream().cuda_stream). */
 pysp_ctx *pysp_ctx_create(int device, void *stream);
 void pysp_ctx_destroy(pysp_ctx *ctx);
+/* Re-bind the context to a caller-owned hipStream_t; NULL means the device's default (null) stream, which
+ * pysp_ctx_create cannot express.  Work already enqueued on the previous stream is waited for, a stream the
+ * context created itself is destroyed.  A torch caller passes torch.cuda.current_stream().cuda_stream so that
+ * library kernels, torch ops, the caching allocator and RCCL collectives are ordered on ONE stream (no host
+ * synchronisation between them).  Every entry point restores the calling thread's current HIP device. */
+int pysp_ctx_set_stream(pysp_ctx *ctx, void *stream);
+void *pysp_ctx_get_stream(pysp_ctx *ctx);
 
 /* The two lookup tables of the restated float32 RGB->Lab used by the AHD homogeneity vote (replaces the
  * table-driven float path of cv2.cvtColor(COLOR_RGB2LAB) called at debayer/ahd.py:58,62): dec receives

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "pysp_ctx_create": (_vp, [_int, _vp]),
     "pysp_ctx_destroy": (None, [_vp]),
     "pysp_ctx_sync": (_int, [_vp]),
+    "pysp_ctx_set_stream": (_int, [_vp, _vp]),
+    "pysp_ctx_get_stream": (_vp, [_vp]),
     "pysp_lab_tables": (_int, [_f32p, _f32p]),
     "pysp_ctx_last_kernel_ms": (_int, [_vp, _f32p]),
     "pysp_ctx_set_kernel_timing": (_int, [_vp, _int]),
@@ -162,6 +164,13 @@ class Context:
     def sync(self) -> None:
         check(lib().pysp_ctx_sync(self.handle))
 
+    def set_stream(self, stream: int) -> None:
+        """Bind to a caller-owned hipStream_t (0 = the device's default stream), e.g. torch's current stream."""
+        check(lib().pysp_ctx_set_stream(self.handle, ctypes.c_void_p(int(stream) or None)))
+
+    def get_stream(self) -> int:
+        return int(lib().pysp_ctx_get_stream(self.handle) or 0)
+
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_float()
         check(lib().pysp_ctx_last_kernel_ms(self.handle, ctypes.byref(ms)))
@@ -191,11 +200,30 @@ class Context:
             pass
 
 
+def default_device() -> int:
+    """Device of the drop-in NumPy API: PYSP_DEVICE if set; else torch's current device when torch has already
+    initialised the GPU in this process; else LOCAL_RANK modulo the device count (one rank per GPU); else 0."""
+    env = os.environ.get("PYSP_DEVICE")
+    if env is not None:
+        return int(env)
+    torch = sys.modules.get("torch")
+    try:
+        if torch is not None and torch.cuda.is_initialized():
+            return int(torch.cuda.current_device())
+    except Exception:
+        pass
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None:
+        n = lib().pysp_device_count()
+        return int(lr) % n if n > 0 else 0
+    return 0
+
+
 def default_context() -> Context:
-    """Per-thread default context on device PYSP_DEVICE (default 0)."""
+    """Per-thread default context (device: `default_device`, fixed at first use)."""
     ctx = getattr(_tls, "ctx", None)
     if ctx is None:
-        ctx = Context(int(os.environ.get("PYSP_DEVICE", "0")))
+        ctx = Context(default_device())
         _tls.ctx = ctx
     return ctx
 

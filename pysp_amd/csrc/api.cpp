@@ -75,9 +75,23 @@ struct pysp_ctx {
     void toc() { if (timing_mode && hipEventRecord(ev1, stream) == hipSuccess) timed = true; }
 };
 
+// Entry points run on the context's device and hand the calling thread's previous HIP device back on every
+// return path: a multi-GPU process that did torch.cuda.set_device(local_rank) keeps its device.
+namespace {
+struct DevGuard {
+    int prev = -1;
+    hipError_t enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == device) { prev = -1; return hipSuccess; }
+        return hipSetDevice(device);
+    }
+    ~DevGuard() { if (prev >= 0) { hipError_t e = hipSetDevice(prev); (void)e; } }
+};
+}  // namespace
 #define CTX_ENTER(ctx)                                                   \
     if (!(ctx)) return fail(PYSP_EBADARG, "null context");               \
-    HIP_TRY(hipSetDevice((ctx)->device))
+    DevGuard _dev_guard;                                                 \
+    HIP_TRY(_dev_guard.enter((ctx)->device))
 
 #define RESERVE(ctx, i, bytes, ptr)                                      \
     do { void* _p; int _r = (ctx)->reserve((i), (bytes), &_p); if (_r) return _r; (ptr) = reinterpret_cast<decltype(ptr)>(_p); } while (0)
@@ -135,7 +149,8 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { fail(PYSP_EHIP, "no HIP device available (%s); libpysp_hip has no CPU fallback", hipGetErrorString(e)); return nullptr; }
     if (device < 0 || device >= n) { fail(PYSP_EBADARG, "device %d out of range [0,%d)", device, n); return nullptr; }
-    if ((e = hipSetDevice(device)) != hipSuccess) { fail(PYSP_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
+    DevGuard guard;
+    if ((e = guard.enter(device)) != hipSuccess) { fail(PYSP_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
     pysp_ctx* c = new pysp_ctx();
     c->device = device;
     if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
@@ -159,8 +174,9 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
 
 void pysp_ctx_destroy(pysp_ctx* c) {
     if (!c) return;
-    hipError_t e = hipSetDevice(c->device); (void)e;
-    if (c->stream) { e = hipStreamSynchronize(c->stream); (void)e; }
+    DevGuard guard;
+    hipError_t e = guard.enter(c->device); (void)e;
+    e = hipStreamSynchronize(c->stream); (void)e;
     for (int i = 0; i < pysp_ctx::NSLOT; i++) if (c->slot[i]) { e = hipFree(c->slot[i]); (void)e; }
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
     if (c->labtab) { e = hipFree(c->labtab); (void)e; }
@@ -176,6 +192,18 @@ int pysp_ctx_sync(pysp_ctx* ctx) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PYSP_OK;
 }
+
+int pysp_ctx_set_stream(pysp_ctx* ctx, void* stream) {
+    CTX_ENTER(ctx);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (s == ctx->stream && !ctx->own_stream) return PYSP_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));          // work already enqueued on the old stream finishes before the workspace is reused
+    if (ctx->own_stream) { HIP_TRY(hipStreamDestroy(ctx->stream)); ctx->own_stream = false; }
+    ctx->stream = s;                                      // NULL = the device's default stream
+    ctx->timed = false; ctx->tl.n = 0;
+    return PYSP_OK;
+}
+void* pysp_ctx_get_stream(pysp_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 
 int pysp_ctx_last_kernel_ms(pysp_ctx* ctx, float* ms) {
     CTX_ENTER(ctx);

@@ -37,15 +37,27 @@ def _warp_rectilinear(image: np.ndarray, data: bytes, scale: float, prior) -> bo
         return False
     coeffs = np.array([unpack(">6d", data[4 + 48 * p: 4 + 48 * (p + 1)]) for p in range(planes)], dtype=np.float64)
     cx, cy = unpack(">2d", data[4 + 48 * planes: 4 + 48 * planes + 16])
-    if image.dtype != np.float32 or not image.flags.c_contiguous:
-        raise ValueError("apply_opcode_3_warp works in place on a C-contiguous float32 (H, W, 3) image")
     H, W, _ = image.shape
-    cptr = coeffs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    if prior is None:      # table evaluated inside the remap kernel, never materialised
-        _lib.check(_lib.lib().pysp_warp_rectilinear_f32(_lib.default_context().handle, _lib.ptr(image), H, W, cptr, planes, cx, cy, scale))
-    else:                  # seeded tables (compute_offset_remapping_table) from the prior mapping
-        pr = np.ascontiguousarray(prior, dtype=np.float32)
-        _lib.check(_lib.lib().pysp_warp_rectilinear_prior_f32(_lib.default_context().handle, _lib.ptr(image), H, W, cptr, planes, cx, cy, scale, _lib.ptr(pr)))
+    L, ctx = _lib.lib(), _lib.default_context()
+    pr_all = None if prior is None else np.asarray(prior, dtype=np.float32)
+    # The kernels work on C-contiguous float32 (H, W, 3) images.  The reference works in place on whatever it is handed --
+    # the flipped / rot90 views image.py:181 returns for non-RGGB sensors, any plane count equal to the opcode's -- so
+    # anything else is warped through a contiguous float32 copy, three planes at a time (a short last group repeats its
+    # final plane), and written back through the view: same in-place semantics.
+    direct = planes == 3 and image.dtype == np.float32 and image.flags.c_contiguous
+    for p0 in range(0, planes, 3):
+        idx = [min(p0 + k, planes - 1) for k in range(3)]
+        buf = image if direct else np.ascontiguousarray(image[:, :, idx], dtype=np.float32)
+        cf = np.ascontiguousarray(coeffs[idx])
+        cptr = cf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        if pr_all is None:      # table evaluated inside the remap kernel, never materialised
+            _lib.check(L.pysp_warp_rectilinear_f32(ctx.handle, _lib.ptr(buf), H, W, cptr, 3, cx, cy, scale))
+        else:                   # seeded tables (compute_offset_remapping_table) from the prior mapping
+            pr = np.ascontiguousarray(pr_all if direct else pr_all[:, :, idx, :])
+            _lib.check(L.pysp_warp_rectilinear_prior_f32(ctx.handle, _lib.ptr(buf), H, W, cptr, 3, cx, cy, scale, _lib.ptr(pr)))
+        if not direct:
+            n = min(3, planes - p0)
+            image[:, :, p0:p0 + n] = buf[:, :, :n]
     return True
 
 

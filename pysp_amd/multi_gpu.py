@@ -146,11 +146,11 @@ def ahd_halo_rows(stages: int) -> int:
     return 8 + 4 * max(0, int(stages))
 
 
-def _settle(pipe) -> None:
-    """The library's kernels run on the pipeline's own stream, tensor copies and collectives on torch's: join both."""
-    pipe.sync()
-    if getattr(pipe.device, "type", "cpu") == "cuda":
-        pipe.torch.cuda.synchronize(pipe.device)
+def _settle(pipe, via_host: bool) -> None:
+    """DevicePipeline enqueues on torch's current stream, so kernels, tensor copies and RCCL collectives are already
+    ordered.  Only the host-staged rehearsal path (gloo) reads device data from the host and needs it finished."""
+    if via_host:
+        pipe.sync()
 
 
 def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0,
@@ -174,7 +174,7 @@ def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, st
     del rgb, sub
     if world > 1:
         import torch.distributed as dist
-        _settle(pipe)
+        _settle(pipe, via_host)
         if exchange == "needed":
             s0, s1 = pipe.warp_source_rows(H, W, coeffs, centre, y0, y1, scale)
             mine = torch.tensor([s0, s1], dtype=torch.int64, device="cpu" if via_host else pipe.device)
@@ -186,7 +186,6 @@ def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, st
             allgather_bands(full, bands, rank, group, via_host)
         else:
             raise ValueError("exchange must be 'needed' or 'allgather'")
-        _settle(pipe)
     out = torch.empty_like(full)
     pipe.warp_rows(full, coeffs, centre, y0, y1, out, scale)
     pipe.sync()

@@ -1,7 +1,10 @@
 """Device-resident pipelines for batch callers (frames stay in HBM; torch is only the allocator).
 
-Each method takes/returns torch CUDA tensors and enqueues on this object's HIP stream through the
-`*_dev` entry points of the C ABI.  Nothing is copied to the host.
+Each method takes/returns torch CUDA tensors and enqueues through the `*_dev` entry points of the C ABI
+on TORCH'S CURRENT STREAM for the device (the context is re-bound to it at every call,
+`pysp_ctx_set_stream`): library kernels, torch ops on the same tensors, the caching allocator's reuse
+of freed blocks and RCCL collectives are therefore ordered like any other torch work -- no host
+synchronisation is needed between them, and none is done.  Nothing is copied to the host.
 
     pipe = DevicePipeline(0)
     srgb = pipe.demosaic_to_srgb(bayer_dev, wb, M)                 # README.md:55-63 recipe, fused
@@ -30,12 +33,18 @@ class DevicePipeline:
         self.device = torch.device("cuda", device)
         self.ctx = _lib.Context(device)
         self.L = _lib.lib()
+        self._stream = -1
+        self._enter()
 
-    # every tensor handed in was produced on torch's current stream: make our stream wait for it
+    # every tensor handed in was produced on (or made visible to) torch's current stream: enqueue there too
     def _enter(self):
-        self.torch.cuda.current_stream(self.device).synchronize()
+        s = int(self.torch.cuda.current_stream(self.device).cuda_stream)
+        if s != self._stream:
+            self.ctx.set_stream(s)
+            self._stream = s
 
     def sync(self):
+        """Wait for everything enqueued so far (only needed before host-side reads through raw pointers)."""
         self.ctx.sync()
 
     def _check_bayer(self, bayer):

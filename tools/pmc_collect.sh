@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects hardware counters for one bench.py workload, one rocprofv3 --pmc pass per counter group (a pass
-# holds only counters that fit the hardware together; --pmc is never combined with other trace domains).
+# holds only counters that fit the hardware together).  A pass combines --pmc with --kernel-trace only (for the kernel
+# names), never with the sys/runtime/hip/hsa/memory-copy/marker trace domains.
 # Usage on the GPU box (through gpurun):  bash tools/pmc_collect.sh <tag> [bench.py args...]
 # Result: gpurun_out/pmc_<tag>/<group>/..._counter_collection.csv, summarised by tools/pmc_summary.py.
 set -eo pipefail
