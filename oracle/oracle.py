@@ -35,8 +35,10 @@ def _cpu_has_fma() -> bool:
 
 def build(force: bool = False) -> None:
     """Compile the C restatement (and nothing else) with the recipe in oracle/Makefile."""
-    if force or not (os.path.exists(os.path.join(_HERE, "liboracle.so"))
-                     and os.path.exists(os.path.join(_HERE, "liboracle_fma.so"))):
+    libs = [os.path.join(_HERE, n) for n in ("liboracle.so", "liboracle_fma.so")]
+    src = os.path.join(_HERE, "pysp_oracle.c")
+    stale = not all(os.path.exists(p) for p in libs) or any(os.path.getmtime(p) < os.path.getmtime(src) for p in libs)
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
 
 
@@ -161,6 +163,18 @@ def rgb2lab(rgb: np.ndarray) -> np.ndarray:
     a = _f32(rgb)
     out = np.empty_like(a)
     _chk(lib().orc_rgb2lab(_p(a), ctypes.c_size_t(a.size // 3), _p(out)), "rgb2lab")
+    return out
+
+
+def set_lab_mode(mode: int) -> None:
+    """0: closed-form Lab with table-driven pow / cbrt (what the product computes); 1: the OpenCV 4.10 LUT + trilinear
+    restatement.  Process-wide switch of the oracle; used by tools/lab_flip_rate.py and the Lab tests only."""
+    _chk(lib().orc_set_lab_mode(int(mode)), "set_lab_mode")
+
+
+def cv410_lut() -> np.ndarray:
+    out = np.empty((33, 33, 33, 3), np.int16)
+    _chk(lib().orc_cv410_lut(_p(out, ctypes.c_int16)), "cv410_lut")
     return out
 
 

@@ -163,7 +163,8 @@ static inline float lab_lut(float (*tab)[4], int nb, int loexp, float x) {
 static inline float lab_pow24(float v) { return lab_lut(lab_dec_tab, LAB_DEC_NB, LAB_DEC_LOEXP, v); }   /* v in (0.04045, 1]: ((v+0.055)/1.055)^2.4 */
 static inline float lab_cbrt(float x) { return lab_lut(lab_cb_tab, LAB_CB_NB, LAB_CB_LOEXP, x); }        /* x in (0.008856, 2) */
 static inline float lab_decode(float v) {
-    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); /* OpenCV clips the float input to [0,1] */
+    v = v > 0.0f ? v : 0.0f; /* OpenCV clips the float input to [0,1] with max/min: a NaN comes out as 0 (as v_med3_f32 gives on the GPU) */
+    v = v < 1.0f ? v : 1.0f;
     return v <= 0.04045f ? v * 0.07739938f /* 1/12.92 */ : lab_pow24(v);
 }
 int orc_lab_tables(float *dec /* LAB_DEC_N*4 */, float *cb /* LAB_CB_N*4 */) {
@@ -192,10 +193,84 @@ static inline void rgb2lab_px(float R, float G, float B, float *L, float *a, flo
     *a = 500.0f * (fx - fy);
     *b = 200.0f * (fy - fz);
 }
+/* ------------------------------------------------------------------------------------------
+ * Second restatement of the same call: OpenCV 4.10's DEFAULT float32 path for sRGB input with the built-in
+ * coefficients (modules/imgproc/src/color_lab.cpp, RGB2Lab_f::operator() with useInterpolation), restated from
+ * memory of that source, UNPINNED like the first:
+ *   clip to [0,1] (min/max: NaN -> 0) -> iv = cvRound(v * 2^14) -> 33^3 grid of int16 Lab values (closed-form Lab of
+ *   applyGamma(p/32) in float32, scaled to 14 bits: L*2^14/100, (a+128)*2^14/256, (b+128)*2^14/256) -> trilinear
+ *   interpolation in fixed point (cell = iv >> 9, position in the cell = (iv >> 5) & 15, weights = products of three
+ *   4-bit factors, CV_DESCALE by 12 bits) -> L = l*100/2^14, a = a'*256/2^14 - 128, b likewise.
+ * Output is therefore quantised (L in steps of 100/16384, a and b in steps of 1/64).  orc_set_lab_mode(1) makes
+ * every Lab conversion of this library (orc_rgb2lab and the AHD homogeneity metric) use it; tools/lab_flip_rate.py
+ * measures how many H/V decisions that changes.  The product follows mode 0. */
+static int g_lab_mode = 0;
+static int16_t cv410_lut[33][33][33][3];   /* [B][G][R] grid point */
+static int cv410_ready = 0;
+static void cv410_build(void) {
+    static const double white[3] = {0.950456, 1.0, 1.088754};
+    static const double xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    float C[9], gam[33];
+    for (int i = 0; i < 9; i++) C[i] = (float)((i / 3 == 1 ? 1.0 : 1.0 / white[i / 3]) * xyz[i]);
+    for (int p = 0; p < 33; p++) {
+        float x = (float)p / 32.0f;
+        gam[p] = x <= 0.04045f ? x / 12.92f : (float)pow((double)((x + 0.055f) / 1.055f), 2.4);
+    }
+    const float lthresh = 216.0f / 24389.0f, lscale = 841.0f / 108.0f, lbias = 16.0f / 116.0f, kap = 24389.0f / 27.0f;
+    for (int r = 0; r < 33; r++)
+        for (int q = 0; q < 33; q++)
+            for (int p = 0; p < 33; p++) {
+                float R = gam[p], G = gam[q], B = gam[r];
+                float X = (R * C[0] + G * C[1]) + B * C[2], Y = (R * C[3] + G * C[4]) + B * C[5], Z = (R * C[6] + G * C[7]) + B * C[8];
+                float FX = X > lthresh ? (float)cbrt((double)X) : fmaf(X, lscale, lbias);
+                float FY = Y > lthresh ? (float)cbrt((double)Y) : fmaf(Y, lscale, lbias);
+                float FZ = Z > lthresh ? (float)cbrt((double)Z) : fmaf(Z, lscale, lbias);
+                float L = Y > lthresh ? 116.0f * FY - 16.0f : kap * Y;
+                float a = 500.0f * (FX - FY), b = 200.0f * (FY - FZ);
+                cv410_lut[r][q][p][0] = (int16_t)lrintf(16384.0f * L / 100.0f);
+                cv410_lut[r][q][p][1] = (int16_t)lrintf(16384.0f * (a + 128.0f) / 256.0f);
+                cv410_lut[r][q][p][2] = (int16_t)lrintf(16384.0f * (b + 128.0f) / 256.0f);
+            }
+    cv410_ready = 1;
+}
+int orc_set_lab_mode(int mode) {
+    if (mode < 0 || mode > 1) return ORC_EBADARG;
+    if (mode == 1 && !cv410_ready) cv410_build();
+    g_lab_mode = mode;
+    return ORC_OK;
+}
+int orc_cv410_lut(int16_t *out /* 33*33*33*3 */) {
+    if (!cv410_ready) cv410_build();
+    memcpy(out, cv410_lut, sizeof(cv410_lut));
+    return ORC_OK;
+}
+static inline int cv410_q(float v) {
+    v = v > 0.0f ? v : 0.0f;   /* max(v, 0): a NaN comes out as 0 */
+    v = v < 1.0f ? v : 1.0f;
+    return (int)lrintf(v * 16384.0f);
+}
+static inline void rgb2lab_px_cv410(float R, float G, float B, float *L, float *a, float *b) {
+    int c[3] = {cv410_q(R), cv410_q(G), cv410_q(B)}, t[3], f[3], acc[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) { t[k] = c[k] >> 9; f[k] = (c[k] >> 5) & 15; }
+    for (int k = 0; k < 8; k++) {
+        int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+        int w = (dx ? f[0] : 16 - f[0]) * (dy ? f[1] : 16 - f[1]) * (dz ? f[2] : 16 - f[2]);
+        int px = t[0] + dx > 32 ? 32 : t[0] + dx, py = t[1] + dy > 32 ? 32 : t[1] + dy, pz = t[2] + dz > 32 ? 32 : t[2] + dz;
+        const int16_t *e = cv410_lut[pz][py][px];
+        acc[0] += e[0] * w; acc[1] += e[1] * w; acc[2] += e[2] * w;
+    }
+    for (int k = 0; k < 3; k++) acc[k] = (acc[k] + (1 << 11)) >> 12;
+    *L = (float)acc[0] * (100.0f / 16384.0f);
+    *a = (float)acc[1] * (256.0f / 16384.0f) - 128.0f;
+    *b = (float)acc[2] * (256.0f / 16384.0f) - 128.0f;
+}
+static inline void rgb2lab_any(float R, float G, float B, float *L, float *a, float *b) {
+    if (g_lab_mode == 1) rgb2lab_px_cv410(R, G, B, L, a, b); else rgb2lab_px(R, G, B, L, a, b);
+}
 int orc_rgb2lab(const float *rgb, size_t npx, float *lab) {
 #pragma omp parallel for
     for (size_t i = 0; i < npx; i++)
-        rgb2lab_px(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], &lab[3 * i], &lab[3 * i + 1], &lab[3 * i + 2]);
+        rgb2lab_any(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], &lab[3 * i], &lab[3 * i + 1], &lab[3 * i + 2]);
     return ORC_OK;
 }
 int orc_lab_pow24(const float *v, size_t n, float *out) { for (size_t i = 0; i < n; i++) out[i] = lab_pow24(v[i]); return ORC_OK; }
@@ -627,10 +702,10 @@ static int homogeneity_map(const float *r, const float *g, const float *b, int H
         if (hdr) {
             float luma = 0.2126f * sr + 0.7152f * sg + 0.0722f * sb; /* :55 */
             sr = sr / (1.0f + sr); sg = sg / (1.0f + sg); sb = sb / (1.0f + sb); /* :57 */
-            rgb2lab_px(sr, sg, sb, &L, &A, &B);
+            rgb2lab_any(sr, sg, sb, &L, &A, &B);
             L = luma; /* :59 */
         } else {
-            rgb2lab_px(sr, sg, sb, &L, &A, &B);
+            rgb2lab_any(sr, sg, sb, &L, &A, &B);
         }
         lab[3 * i] = L; lab[3 * i + 1] = A; lab[3 * i + 2] = B;
     }

@@ -232,7 +232,28 @@ def main():
             rb = RawBayerData()
             rb.sensor_scaled = bay; rb.cam_wb = FakeWb(MULT, mat); rb.current_ev = 9.0; rb.sensor_pattern = pat
             cfa[f"eag_{pat.name}"] = np.ascontiguousarray(rb.demosaic(QualityDemosaic.Fast).image)
-        save("g8_cfa_patterns", {"ref": "image.py:143-152,181,185-197", "cv2_restated": True, "io_stubs": True}, **cfa)
+            cfa[f"draft_{pat.name}"] = np.ascontiguousarray(rb.demosaic(QualityDemosaic.Draft).image)
+            cfa[f"ahd1_{pat.name}"] = np.ascontiguousarray(rb.demosaic(QualityDemosaic.Best, 1).image)
+        save("g8_cfa_patterns", {"ref": "image.py:143-152,181,185-197", "cv2_restated": True, "colour_shim": True, "io_stubs": True}, **cfa)
+
+        # The same AHD frames with the OTHER Lab restatement standing in for cv2.cvtColor (OpenCV 4.10's LUT + trilinear
+        # float path, oracle/cv2_restated.py LAB_MODE "cv410_lut"): pins the oracle's lab mode 1 and whatever follows it.
+        cv2_restated.LAB_MODE = "cv410_lut"
+        try:
+            for (H, W), hdr in (((32, 48), False), ((34, 50), True)):
+                bay = scene(H, W, 1000 + H, scale=3.0 if hdr else 1.0)
+                if not hdr:
+                    bay = np.clip(bay, 0, 1)
+                mat = MatXyzToCamera(XYZ2CAM[0], oracle.xy_to_XYZ(WHITES_XY[0]))
+                out = {"bayer": bay, "mult": MULT, "xyz2cam": XYZ2CAM[0], "white_xyz": oracle.xy_to_XYZ(WHITES_XY[0])}
+                for st in (0, 1):
+                    im = RawRggbBayerData(bay, FakeWb(MULT, mat), 10.0, 1.0)
+                    im.set_hdr(hdr)
+                    out[f"ahd{st}"] = im.demosaic(QualityDemosaic.Best, st).image
+                save(f"g8_labmode_cv410lut_{H}x{W}{'_hdr' if hdr else ''}",
+                     {"ref": "debayer/ahd.py:32-67", "cv2_restated": True, "lab_mode": "cv410_lut", "colour_shim": True, "io_stubs": True, "hdr": hdr}, **out)
+        finally:
+            cv2_restated.LAB_MODE = "closed_form"
 
         # resample_channel / resample_g standalone
         sub = rng.random((9, 7), dtype=np.float32); gs = rng.random((9, 7), dtype=np.float32); hf = (rng.random((18, 14), dtype=np.float32) - 0.5)

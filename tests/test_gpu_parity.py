@@ -132,6 +132,8 @@ def test_cfa_patterns_golden(wbobj):
         out = rb.demosaic(QualityDemosaic.Fast)
         assert np.array_equal(out.image, d[f"eag_{pat.name}"]), pat
         assert out.current_ev == 9.0 and out.mat_xyz is not None
+        assert np.array_equal(rb.demosaic(QualityDemosaic.Draft).image, d[f"draft_{pat.name}"]), pat
+        assert np.array_equal(rb.demosaic(QualityDemosaic.Best, 1).image, d[f"ahd1_{pat.name}"]), pat
 
 
 def test_unknown_quality_raises(wbobj):

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Record what the REAL OpenCV does for the nine cv2 calls on pySP's hot path.  Run this wherever
+`opencv_python==4.10.0.84` (the reference's pin, requirements.txt:5) is installed -- the build image has no cv2:
+
+    python tools/gen_cv2_goldens.py                      # writes tests/golden/cv2_calls.npz
+    python tools/gen_cv2_goldens.py --reference /path/to/pySP   # additionally the whole reference pipeline with real cv2
+                                                                 # on the G8 frames -> tests/golden/cv2_g8_*.npz
+
+Needs only numpy, cv2 and the fixtures already committed under tests/golden/ (inputs are derived from them, so the
+file is reproducible); `--reference` needs an importable checkout of the reference (+ its own dependencies).
+tests/test_cv2_goldens.py consumes the files when they exist (skipped otherwise) and compares every restatement in
+oracle/cv2_restated.py and oracle/pysp_oracle.c -- and, on the GPU box, the kernels -- with the real outputs.
+
+Call sites (relative to the reference): debayer/ahd.py:58,62 (cvtColor), :64,77-80 (copyMakeBorder), :120-121
+(GaussianBlur), :133-134 (blur), :151 (medianBlur); debayer/edge_assisted_gaussian.py:86-87, :141,143 (filter2D),
+:156,170,184; debayer/fast_resize.py:28-29,39 (resize); dng_warp_corr/chan_distortion_corr.py:94-97 (remap LANCZOS4);
+corr_ca/ca_removal.py:100-128 (remap LINEAR).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def call_inputs():
+    """Inputs of every recorded call, derived from committed fixtures only (shared with the consuming test)."""
+    rng = np.random.default_rng(410)
+    g8 = np.load(os.path.join(GOLDEN, "g8_demosaic_34x50.npz"))
+    g8h = np.load(os.path.join(GOLDEN, "g8_demosaic_34x50_hdr.npz"))
+    g2 = np.load(os.path.join(GOLDEN, "g2_rgbg_kernel.npz"))
+    g10 = np.load(os.path.join(GOLDEN, "g10_warp_apply.npz"))
+    bay = g8["bayer"]
+    r, g1, b, g2p = (np.ascontiguousarray(bay[0::2, 0::2]), np.ascontiguousarray(bay[0::2, 1::2]),
+                     np.ascontiguousarray(bay[1::2, 1::2]), np.ascontiguousarray(bay[1::2, 0::2]))
+    H, W = bay.shape
+    inp = {"plane_r": r, "plane_b": b}
+    inp["green_full"] = np.ascontiguousarray(g8["ahd0"][..., 1])
+    inp["kernels"] = np.stack([g2[f"pos{p}_k{i}"] for p in range(4) for i in range(4)])          # (16,3,3) float64
+    lin = g8["ahd1_lin"]
+    linh = g8h["ahd1_lin"]
+    cube = (rng.random((64, 64, 3), dtype=np.float32) * np.float32(1.5) - np.float32(0.25)).astype(np.float32)
+    grey = np.repeat(np.geomspace(1e-6, 1.0, 4096).astype(np.float32)[None, :, None], 3, axis=2)
+    fine = (rng.random((128, 128, 3), dtype=np.float32) * np.float32(0.02) + np.float32(0.2)).astype(np.float32)   # neighbours a few 1e-3 apart: the vote's regime
+    inp["lab_lin"] = np.ascontiguousarray(lin); inp["lab_hdr_tonemapped"] = np.ascontiguousarray(linh / (1 + linh))
+    inp["lab_cube"] = cube; inp["lab_grey"] = np.ascontiguousarray(grey); inp["lab_fine"] = fine
+    inp["vote_map"] = rng.integers(0, 10, (H, W)).astype(np.float32)
+    inp["chroma_diff"] = np.ascontiguousarray(g8["ahd0"][..., 0] - g8["ahd0"][..., 1])
+    inp["quarter_rgb"] = np.ascontiguousarray(np.stack([r, (g1 + g2p) / 2, b], axis=-1))
+    img = np.ascontiguousarray(g10["image"][..., 0])
+    h, w = img.shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    inp["remap_src"] = img
+    inp["remap_x"] = np.clip(xx + np.float32(0.9) * np.sin(yy / np.float32(5)) - np.float32(0.3), 0, w - 1).astype(np.float32)
+    inp["remap_y"] = np.clip(yy + np.float32(1.1) * np.cos(xx / np.float32(7)) + np.float32(0.2), 0, h - 1).astype(np.float32)
+    return inp, (H, W)
+
+
+def record_calls(cv2):
+    inp, (H, W) = call_inputs()
+    out = {}
+    r, b = inp["plane_r"], inp["plane_b"]
+    out["cmb_1111"] = cv2.copyMakeBorder(r, 1, 1, 1, 1, cv2.BORDER_REFLECT)
+    out["cmb_0101"] = cv2.copyMakeBorder(r, 0, 1, 0, 1, cv2.BORDER_REFLECT)
+    out["cmb_1010"] = cv2.copyMakeBorder(b, 1, 0, 1, 0, cv2.BORDER_REFLECT)
+    out["gauss"] = cv2.GaussianBlur(inp["green_full"], (3, 3), 1.0)
+    out["filter2d"] = np.stack([cv2.filter2D(r, -1, k) for k in inp["kernels"]])
+    for k in ("lab_lin", "lab_hdr_tonemapped", "lab_cube", "lab_grey", "lab_fine"):
+        out[k + "_out"] = cv2.cvtColor(inp[k], cv2.COLOR_RGB2LAB)
+    out["blur"] = cv2.blur(inp["vote_map"], (3, 3))
+    out["median5"] = cv2.medianBlur(inp["chroma_diff"], 5)
+    out["resize"] = cv2.resize(inp["quarter_rgb"], (W, H))
+    out["remap_lanczos4"] = cv2.remap(inp["remap_src"], inp["remap_x"], inp["remap_y"], cv2.INTER_LANCZOS4)
+    out["remap_linear"] = cv2.remap(inp["remap_src"], inp["remap_x"], inp["remap_y"], cv2.INTER_LINEAR)
+    return out
+
+
+def record_reference(cv2, ref_path):
+    """The reference's own demosaic on the G8 frames with the real cv2 (needs the reference importable as package pySP)."""
+    parent, name = os.path.split(os.path.abspath(ref_path.rstrip("/")))
+    if name != "pySP":
+        import tempfile
+        farm = tempfile.mkdtemp(prefix="pysp_farm_")
+        os.symlink(os.path.abspath(ref_path), os.path.join(farm, "pySP"))
+        parent = farm
+    sys.path.insert(0, parent)
+    from pySP.const import QualityDemosaic
+    from pySP.image import RawRggbBayerData
+    from pySP.wb_cct.helpers_cam_mat import MatXyzToCamera
+
+    class FakeWb:
+        def __init__(self, mult, mat): self._m, self._mat = np.array(mult, dtype=np.float32), mat
+        def get_reciprocal_multipliers(self): return np.copy(1.0 / self._m)
+        def get_matrix(self): return self._mat
+        def copy(self): return FakeWb(self._m, self._mat)
+    for name in ("g8_demosaic_32x48", "g8_demosaic_34x50", "g8_demosaic_32x48_hdr", "g8_demosaic_34x50_hdr"):
+        d = np.load(os.path.join(GOLDEN, name + ".npz"))
+        hdr = bool(json.loads(str(d["meta"]))["hdr"])
+        mat = MatXyzToCamera(d["xyz2cam"], d["white_xyz"])
+        out = {"bayer": d["bayer"], "mult": d["mult"], "xyz2cam": d["xyz2cam"], "white_xyz": d["white_xyz"]}
+
+        def mk():
+            im = RawRggbBayerData(d["bayer"], FakeWb(d["mult"], mat), 10.0, 1.0)
+            im.set_hdr(hdr)
+            return im
+        if not hdr:
+            out["draft"] = mk().demosaic(QualityDemosaic.Draft).image
+            out["eag"] = mk().demosaic(QualityDemosaic.Fast).image
+        for st in (0, 1, 3):
+            out[f"ahd{st}"] = mk().demosaic(QualityDemosaic.Best, st).image
+        out["meta"] = np.array(json.dumps({"cv2": cv2.__version__, "hdr": hdr, "source": name}))
+        np.savez_compressed(os.path.join(GOLDEN, "cv2_" + name + ".npz"), **out)
+        print("wrote cv2_" + name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default=None, help="path of a pySP checkout: also record its full demosaic with the real cv2")
+    ap.add_argument("--any-version", action="store_true", help="record even if cv2 is not 4.10.0 (the version is stored in the file)")
+    args = ap.parse_args()
+    try:
+        import cv2
+    except ImportError:
+        sys.exit("gen_cv2_goldens.py needs the real OpenCV (pip install opencv-python==4.10.0.84); it is not available in this environment")
+    if not cv2.__version__.startswith("4.10.0") and not args.any_version:
+        sys.exit(f"cv2 {cv2.__version__} found, the reference pins 4.10.0.84 (pass --any-version to record anyway)")
+    cv2.setNumThreads(1)
+    cv2.ocl.setUseOpenCL(False)
+    out = record_calls(cv2)
+    build = cv2.getBuildInformation()
+    ipp = [l.strip() for l in build.splitlines() if "IPP" in l][:3]
+    out["meta"] = np.array(json.dumps({"cv2": cv2.__version__, "numpy": np.__version__, "ipp": ipp, "cpu_features": cv2.getCPUFeaturesLine()}))
+    np.savez_compressed(os.path.join(GOLDEN, "cv2_calls.npz"), **out)
+    print("wrote tests/golden/cv2_calls.npz:", {k: v.shape for k, v in out.items() if k != "meta"})
+    if args.reference:
+        record_reference(cv2, args.reference)
+
+
+if __name__ == "__main__":
+    main()
