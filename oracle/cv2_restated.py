@@ -14,7 +14,7 @@ cvtColor(RGB2LAB) exists twice, both in NumPy with no call into the C oracle:
   * LAB_MODE = "cv410_lut": OpenCV 4.10's default float32 path for sRGB input as published in
     modules/imgproc/src/color_lab.cpp (RGB2Lab_f with useInterpolation): clip, cvRound(v * 2^14), 33^3 int16
     LUT of closed-form Lab at the grid points, fixed-point trilinear interpolation, rescale.  Restated FROM
-    MEMORY of that source (unpinnable here); tools/lab_flip_rate.py reports how many AHD decisions differ
+    MEMORY of that source (unpinnable here); tests/lab_flip_rate.py reports how many AHD decisions differ
     between the two, tools/gen_cv2_goldens.py records the real thing wherever cv2 is installed.
 
 Call sites (relative to /root/reference): ahd.py:58,62,64,77-80,120-121,133-134,151;

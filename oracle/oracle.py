@@ -168,7 +168,7 @@ def rgb2lab(rgb: np.ndarray) -> np.ndarray:
 
 def set_lab_mode(mode: int) -> None:
     """0: closed-form Lab with table-driven pow / cbrt (what the product computes); 1: the OpenCV 4.10 LUT + trilinear
-    restatement.  Process-wide switch of the oracle; used by tools/lab_flip_rate.py and the Lab tests only."""
+    restatement.  Process-wide switch of the oracle; used by tests/lab_flip_rate.py and the Lab tests only."""
     _chk(lib().orc_set_lab_mode(int(mode)), "set_lab_mode")
 
 

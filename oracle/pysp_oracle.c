@@ -202,7 +202,7 @@ static inline void rgb2lab_px(float R, float G, float B, float *L, float *a, flo
  *   interpolation in fixed point (cell = iv >> 9, position in the cell = (iv >> 5) & 15, weights = products of three
  *   4-bit factors, CV_DESCALE by 12 bits) -> L = l*100/2^14, a = a'*256/2^14 - 128, b likewise.
  * Output is therefore quantised (L in steps of 100/16384, a and b in steps of 1/64).  orc_set_lab_mode(1) makes
- * every Lab conversion of this library (orc_rgb2lab and the AHD homogeneity metric) use it; tools/lab_flip_rate.py
+ * every Lab conversion of this library (orc_rgb2lab and the AHD homogeneity metric) use it; tests/lab_flip_rate.py
  * measures how many H/V decisions that changes.  The product follows mode 0. */
 static int g_lab_mode = 0;
 static int16_t cv410_lut[33][33][33][3];   /* [B][G][R] grid point */

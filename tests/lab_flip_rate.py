@@ -9,7 +9,7 @@ AHD thresholds on these values with `<=` (debayer/ahd_homogeneity_cython.pyx:56-
 synthetic 24 MP frame and on pure noise: how many homogeneity counts differ, how many H/V decisions flip, and how far the
 demosaiced / sRGB output moves.  Numbers quoted in DESIGN.md section 3.
 
-    python tools/lab_flip_rate.py [--H 4000 --W 6000] [--hdr]
+    python tests/lab_flip_rate.py [--H 4000 --W 6000] [--hdr]
 """
 import argparse
 import json
