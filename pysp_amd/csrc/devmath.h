@@ -51,10 +51,15 @@ DEVI int b_1011(int p, int n) {
     return r < 0 ? 0 : (r >= n ? n - 1 : r);
 }
 
-// np.clip(x, 0, 1) (transform.py:6-19) as one v_med3_f32: on gfx950 compares/selects/min/max/med3 issue at half
-// the rate of f32 add/mul/fma (4 vs 2 cycles per wave, tools/ubench_valu2.hip), so one med3 replaces four slow ops.
-// Identical to the compare form for every non-NaN input up to the sign of a zero result.
-DEVI float clip01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+// Clip to [0,1] as one v_med3_f32: on gfx950 compares/selects/min/max/med3 issue at half the rate of f32 add/mul/fma
+// (4 vs 2 cycles per wave, tools/ubench_valu2.hip), so one med3 replaces four slow ops.  Identical to the compare
+// form for every non-NaN input up to the sign of a zero result.  A (quiet) NaN comes out as 0 (v_med3 falls back to
+// min3, and v_min returns its non-NaN operand), which is
+//   * what the restated cv2.cvtColor wants: OpenCV clips its float input with max(.,0) / min(.,1) (clip01_cv), and
+//   * NOT what np.clip does (transform.py:6-19): np.clip propagates NaN -> clip01_np below, or, in the fused colour
+//     tail, one NaN test per pixel (the float64 matrix spreads a NaN of any channel to all three outputs anyway).
+DEVI float clip01_cv(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+DEVI float clip01_np(float v) { float c = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); return v != v ? v : c; }
 
 // ---- 3x3 colour matrix, transform.py:52-53: float64 accumulate in dgemm order, one rounding ----
 struct Ccm { double m[9]; };
@@ -85,7 +90,7 @@ DEVI float lab_lut(const float4* tab, float x) {
     return __builtin_fmaf(__builtin_fmaf(e.z, fr, e.y), fr, e.x);
 }
 DEVI float lab_decode(LabTab t, float v) {
-    v = clip01(v);
+    v = clip01_cv(v);
     float p = lab_lut<LAB_DEC_NB, LAB_DEC_SLOTS>(t.dec, v);   // both sides are evaluated (no divergence)
     return v <= 0.04045f ? v * 0.07739938f : p;
 }
@@ -125,13 +130,16 @@ DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
     y = __builtin_fma(y, (double)l2 * -6.885798579082628e-09, y);
     return (float)y;
 }
+// NANS: the argument may be NaN and np.where(NaN <= t, ., 1.055 * NaN**e - 0.055) = NaN has to come out (stand-alone
+// lin_srgb_to_srgb on caller data); the fused colour tail handles NaN once per pixel and passes false.
+template <bool NANS = true>
 DEVI float srgb_encode(float x) {
-    x = clip01(x);
-    float p = srgb_pow_5_12(x);   // x <= 0.0031308 (incl. 0 -> inf/NaN inside) is discarded by the select
+    x = NANS ? clip01_np(x) : clip01_cv(x);
+    float p = srgb_pow_5_12(x);   // x <= 0.0031308 (incl. 0 -> inf/NaN inside) is discarded by the select; NaN -> NaN
     return x <= 0.0031308f ? x * 12.92f : 1.055f * p - 0.055f;
 }
 DEVI float srgb_decode(float x) {
-    x = clip01(x);
+    x = clip01_np(x);
     float u = (x + 0.055f) / 1.055f;
     float p = (float)pow((double)u, (double)2.4f);
     return x <= 0.04045f ? x / 12.92f : p;
@@ -140,13 +148,21 @@ DEVI float srgb_decode(float x) {
 // ---- colour tail applied to a camera-RGB pixel at the end of a fused pipeline -------------------
 //   tail 0: none (RawDemosaicData.image)           tail 1: to_lin_srgb (clip + CCM)
 //   tail 2: to_lin_srgb + lin_srgb_to_srgb          tail 3: ... with README.md:157 x/(1+x) in between
+// Non-finite input (e.g. the 0/0 a zero flat field leaves in the mosaic, raw_correction.py:45): np.clip keeps a NaN, the
+// float64 np.dot then makes all three outputs of that pixel NaN, and nothing downstream turns a NaN back into a number;
+// +-Inf clip to 1 / 0 like any other value.  So one test per pixel decides: two unordered compares, and the outputs of a
+// NaN pixel are replaced by NaN at the end (the arithmetic in between runs on the med3-clipped zeros and is discarded).
 DEVI void colour_tail(int tail, const double* M, float& r, float& g, float& b) {
     if (tail == 0) return;
-    float cr = clip01(r), cg = clip01(g), cb = clip01(b);
+    const bool has_nan = __builtin_isunordered(r, g) | (b != b);
+    float cr = clip01_cv(r), cg = clip01_cv(g), cb = clip01_cv(b);
     r = ccm_row(M, cr, cg, cb);
     g = ccm_row(M + 3, cr, cg, cb);
     b = ccm_row(M + 6, cr, cg, cb);
-    if (tail == 1) return;
-    if (tail == 3) { r = r / (1.0f + r); g = g / (1.0f + g); b = b / (1.0f + b); }
-    r = srgb_encode(r); g = srgb_encode(g); b = srgb_encode(b);
+    if (tail >= 2) {
+        if (tail == 3) { r = r / (1.0f + r); g = g / (1.0f + g); b = b / (1.0f + b); }
+        r = srgb_encode<false>(r); g = srgb_encode<false>(g); b = srgb_encode<false>(b);
+    }
+    const float qnan = __int_as_float(0x7fc00000);
+    r = has_nan ? qnan : r; g = has_nan ? qnan : g; b = has_nan ? qnan : b;
 }

@@ -113,6 +113,34 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
     }
 }
 
+// The same vote with nothing taken for granted: all nine cells of each window go through both tests, exactly as
+// pyx:47-58 spells them.  Needed when a Lab value is not finite -- only L can be (HDR mode: L = luma, ahd.py:55,59; a and b
+// come from clipped values) -- because then the comparisons the fast form skips are false (NaN) instead of true.
+template <int DIR>
+DEVI void vote_quad_literal(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
+        float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
+        float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
+        float da1 = ra - wa[n1y][n1x], db1 = rb - wq[n1y][n1x], da2 = ra - wa[n2y][n2x], db2 = rb - wq[n2y][n2x];
+        float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
+        float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
+        int c = 0;
+#pragma unroll
+        for (int wy = 0; wy < 3; wy++)
+#pragma unroll
+            for (int wx = 0; wx < 3; wx++) {
+                const int y = dy + wy, x = dx + wx;
+                float da = wa[y][x] - ra, db = wq[y][x] - rb;
+                bool ok = (wl[y][x] - rl <= el) && (da * da + db * db <= ec);
+                c += ok ? 1 : 0;
+            }
+        cnt[k] = c;
+    }
+}
+
 }  // namespace
 
 struct AhdParams {
@@ -127,7 +155,9 @@ struct AhdParams {
 };
 
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
-template <bool TINY, bool U16>
+// HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs
+// registers: 100 VGPRs (4 waves per SIMD) with it compiled in, 92 (5 waves) without -- the non-HDR kernel stays at 92.
+template <bool TINY, bool U16, bool HDR>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
     // LDS, 30.6 KB per workgroup (five workgroups per CU).  The mosaic planes are dead once P1 and the green reads below are
     // done, and the horizontal g/D planes once the horizontal P2 is: the Lab buffer of both directions lies over them (a barrier
@@ -273,7 +303,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                homog_lab(lt, rr[k], gg[k], bb[k], p.wb, M, p.hdr, labq[k][0], labq[k][1], labq[k][2]);
+                homog_lab(lt, rr[k], gg[k], bb[k], p.wb, M, HDR, labq[k][0], labq[k][1], labq[k][2]);
                 rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
 #ifndef AHD_NO_SB
                 __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
@@ -303,7 +333,11 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_win(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
             int cnt[4];
-            if (dir == 0) vote_quad<0>(wl, wa, wq, cnt); else vote_quad<1>(wl, wa, wq, cnt);
+            // HDR metric: L = luma (ahd.py:55,59) may be NaN or +-Inf, and then the comparisons the fast form takes for granted
+            // are false; the literal nine-cell form is used throughout (a per-wave switch between the two forms was measured
+            // at 155 VGPRs / 3 waves per SIMD; literal only: see the resource table in DESIGN.md)
+            if (HDR) { if (dir == 0) vote_quad_literal<0>(wl, wa, wq, cnt); else vote_quad_literal<1>(wl, wa, wq, cnt); }
+            else { if (dir == 0) vote_quad<0>(wl, wa, wq, cnt); else vote_quad<1>(wl, wa, wq, cnt); }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int yy = vmy + (k >> 1), xx = vmx + (k & 1);
@@ -586,10 +620,15 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
     dim3 ga((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_ahd_select");
     const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
-    if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true>), ga, dim3(NT_A), 0, st, a);
-    else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false>), ga, dim3(NT_A), 0, st, a);
-    else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true>), ga, dim3(NT_A), 0, st, a);
-    else hipLaunchKernelGGL((k_ahd_select<false, false>), ga, dim3(NT_A), 0, st, a);
+#define AHD_LAUNCH(HDRV) \
+    do { \
+        if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true, HDRV>), ga, dim3(NT_A), 0, st, a); \
+        else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false, HDRV>), ga, dim3(NT_A), 0, st, a); \
+        else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true, HDRV>), ga, dim3(NT_A), 0, st, a); \
+        else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV>), ga, dim3(NT_A), 0, st, a); \
+    } while (0)
+    if (hdr) AHD_LAUNCH(true); else AHD_LAUNCH(false);
+#undef AHD_LAUNCH
     if (tl) tl->end(st);
     const float* cur = a.out;
     dim3 gb((W + BTX - 1) / BTX, (H + BTY - 1) / BTY);

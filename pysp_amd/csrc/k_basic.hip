@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_rgb_pointwise(const float* __restrict__
     }
 }
 struct FCcm { Ccm m; int clip; __device__ void operator()(float& r, float& g, float& b) const {
-    float cr = clip ? clip01(r) : r, cg = clip ? clip01(g) : g, cb = clip ? clip01(b) : b;
+    float cr = clip ? clip01_np(r) : r, cg = clip ? clip01_np(g) : g, cb = clip ? clip01_np(b) : b;   // np.clip keeps a NaN (transform.py:6-19)
     r = ccm_row(m.m, cr, cg, cb); g = ccm_row(m.m + 3, cr, cg, cb); b = ccm_row(m.m + 6, cr, cg, cb); } };
 struct FTail { Ccm m; int tail; __device__ void operator()(float& r, float& g, float& b) const { colour_tail(tail, m.m, r, g, b); } };
 struct FEnc { __device__ void operator()(float& r, float& g, float& b) const { r = srgb_encode(r); g = srgb_encode(g); b = srgb_encode(b); } };

@@ -19,6 +19,14 @@ wbobj = default_wb()
 M0 = final_matrix(wbobj.get_matrix())
 
 
+def sprinkle(rng, a):
+    """Quiet NaN / +Inf / -Inf at a few random sites (anywhere, borders included)."""
+    n = int(rng.integers(1, 6))
+    for _ in range(n):
+        a[int(rng.integers(0, a.shape[0])), int(rng.integers(0, a.shape[1]))] = (np.nan, np.inf, -np.inf)[int(rng.integers(0, 3))]
+    return a
+
+
 def frame(rng, H, W):
     kind = rng.integers(0, 7)
     if kind == 0: a = rng.random((H, W))
@@ -42,17 +50,22 @@ while time.time() < t_end:
     else:
         H, W = 2 * int(rng.integers(1, 120)), 2 * int(rng.integers(1, 160))
     bay = frame(rng, H, W)
+    nonfinite = rng.random() < 0.15          # non-finite sites: exact parity is claimed up to (not through) a median stage
+    if nonfinite:
+        bay = sprinkle(rng, bay)
     wb = (1.0 / rng.uniform(0.3, 1.0, 3)).astype(np.float32)
     M = M0 * rng.uniform(0.8, 1.2, (3, 3)) if rng.random() < 0.5 else M0
     case = int(rng.integers(0, 6))
     d = torch.from_numpy(bay).cuda()
     if case == 0:      # AHD with stages / hdr
         stages, hdr = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
+        if nonfinite: stages = 0
         got = pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, hdr, stages); pipe.sync()
         ref = orc.demosaic_ahd(bay, wb, M, hdr, stages)
         tag = f"ahd stages={stages} hdr={hdr}"
     elif case == 1:    # fused pipeline to sRGB, any quality
         q, stages, hdr, rh = int(rng.integers(0, 3)), int(rng.integers(0, 3)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if nonfinite: stages = 0
         got = pipe.demosaic_to_srgb(d, wb, M, q, hdr, stages, rh); pipe.sync()
         ref = orc.pipeline_srgb(bay, wb, M, q, hdr, stages, rh)
         tag = f"srgb q={q} stages={stages} hdr={hdr} reinhard={rh}"
@@ -69,7 +82,7 @@ while time.time() < t_end:
         ref = orc.pipeline_srgb(orc.bayer_normalize(raw, black, sat), wb, M, q, False, 1, False)
         tag = f"u16 q={q}"
     elif case == 4:    # CA removal with random smooth quadrant fields
-        if H < 4 or W < 4:
+        if H < 4 or W < 4 or nonfinite:
             n += 1; continue
         h, w = H // 2, W // 2
         yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
@@ -85,6 +98,8 @@ while time.time() < t_end:
     else:              # raw HDR fusion
         K = int(rng.integers(2, 6))
         frames = [np.clip(frame(rng, H, W), 0, 1) for _ in range(K)]
+        if nonfinite:
+            frames[int(rng.integers(0, K))] = sprinkle(rng, frames[0].copy())
         evs = [float(10 + k + rng.uniform(-0.3, 0.3)) for k in range(K)]
         fused, count, _, _ = pipe.fuse_raw([torch.from_numpy(x).cuda() for x in frames], evs, wb); pipe.sync()
         rf, rc = orc.fuse_raw(frames, evs, wb)[:2]

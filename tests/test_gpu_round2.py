@@ -101,3 +101,125 @@ def test_warp_in_place_on_views_and_plane_counts():
     keep = img.copy()
     apply_opcode_3_warp(keep, _opcode_blob(coeffs[:2]))
     assert np.array_equal(keep, img)
+
+
+# ---- non-finite values travel through the path exactly as through the NumPy reference ----------------
+def _poisoned(H, W, seed, scale=1.0):
+    """Synthetic frame with quiet NaN, +Inf and -Inf sites: corners, edges, a 2x2 block, random interior sites."""
+    from pysp_amd.synth import rggb_frame
+    rng = np.random.default_rng(seed)
+    bay = rggb_frame(H, W, seed, scale=scale, clip_hi=scale == 1.0).copy()
+    vals = [np.nan, np.inf, -np.inf]
+    sites = [(0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (0, W // 2), (H // 2, 0), (H - 1, W // 3), (H // 3, W - 1)]
+    sites += [(int(rng.integers(2, H - 2)), int(rng.integers(2, W - 2))) for _ in range(18)]
+    for i, (y, x) in enumerate(sites):
+        bay[y, x] = vals[i % 3]
+    y0, x0 = H // 2 + 1, W // 2 + 3
+    bay[y0:y0 + 2, x0:x0 + 2] = np.nan
+    return bay
+
+
+def _same(got, ref):
+    """Bit-equal where finite, same NaN positions, same signed infinities."""
+    return np.array_equal(got, ref, equal_nan=True)
+
+
+def test_non_finite_mosaic_matches_literal_oracle(orc, wbobj):
+    """NaN (e.g. the 0/0 of raw_correction.py:45) and +-Inf in the mosaic: np.clip keeps NaN (transform.py:6-19), the float64
+    np.dot spreads it over the pixel, build_map counts nothing through a NaN compare (pyx:56-57), the selection multiplies
+    the unselected candidate by 0 (ahd.py:141-145: Inf * 0 = NaN).  GPU == literal oracle, NaN positions included, for
+    Draft / EAG / AHD(0) with and without the HDR metric and every colour tail; with a median stage everywhere except
+    within 4 px of a non-finite pre-median pixel (a median of a window holding NaN is unspecified in OpenCV, too)."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    wb, M = _wbM(orc)
+    pipe = DevicePipeline(0)
+    for (H, W), seed in (((64, 96), 5), ((130, 158), 6)):
+        for hdr in (False, True):
+            bay = _poisoned(H, W, seed, scale=3.0 if hdr else 1.0)
+            d = torch.from_numpy(bay).cuda()
+            if not hdr:
+                for q, fn in ((_lib.QUALITY_DRAFT, orc.demosaic_draft), (_lib.QUALITY_FAST, orc.demosaic_eag)):
+                    raw = fn(bay, wb)
+                    assert np.isnan(raw).any() and np.isinf(raw).any()
+                    assert _same(pipe.demosaic(d, wb, M, q, False, 0).cpu().numpy(), raw), q
+                    assert _same(pipe.batch([d], wb, M, q, False, 0, tail=1)[0].cpu().numpy(), orc.cam_to_rgb(raw, M, True)), q
+                    assert _same(pipe.demosaic_to_srgb(d, wb, M, q, False, 0).cpu().numpy(), orc.pipeline_srgb(bay, wb, M, q, False, 0, False)), q
+            raw = orc.demosaic_ahd(bay, wb, M, hdr, 0)
+            assert np.isnan(raw).any()
+            assert _same(pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, hdr, 0).cpu().numpy(), raw), hdr
+            assert _same(pipe.batch([d], wb, M, _lib.QUALITY_BEST, hdr, 0, tail=1)[0].cpu().numpy(), orc.cam_to_rgb(raw, M, True)), hdr
+            for rh in (False, True):
+                assert _same(pipe.demosaic_to_srgb(d, wb, M, _lib.QUALITY_BEST, hdr, 0, rh).cpu().numpy(),
+                             orc.pipeline_srgb(bay, wb, M, 2, hdr, 0, rh)), (hdr, rh)
+            # one median stage: exact outside the 9x9 neighbourhoods (two chained 5x5 medians) of non-finite pre-median pixels
+            bad = ~np.isfinite(raw).all(axis=-1)
+            near = np.zeros_like(bad)
+            for dy in range(-4, 5):
+                for dx in range(-4, 5):
+                    near |= np.roll(np.roll(np.pad(bad, 4), dy, 0), dx, 1)[4:-4, 4:-4]
+            got = pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, hdr, 1).cpu().numpy()
+            ref = orc.demosaic_ahd(bay, wb, M, hdr, 1)
+            assert near.mean() < 0.5 and np.array_equal(got[~near], ref[~near]), hdr
+
+
+def test_non_finite_from_the_products_own_flat_field(orc, wbobj):
+    """raw_correction.py:45 on a region where image and flat are both zero leaves NaN in the mosaic; that mosaic then goes
+    through the README recipe (drop-in classes), equal to the oracle including the NaN positions."""
+    from pysp_amd.base_types.image_base import RawBayerData_BaseType  # noqa: F401  (import path check)
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawBayerData, RawRggbBayerData
+    from pysp_amd.raw_correction import flat_frame_correction
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    H, W = 72, 104
+    bay = rggb_frame(H, W, 21).copy()
+    flat = np.full((H, W), 0.8, np.float32)
+    bay[20:26, 30:38] = 0.0
+    flat[20:26, 30:38] = 0.0                      # 0 * mean / 0 = NaN
+    flat[50, 60] = 0.0                            # x / 0 = +Inf -> replaced by the channel maximum (raw_correction.py:52)
+    img = RawBayerData(); img.sensor_scaled = bay.copy()
+    fl = RawBayerData(); fl.sensor_scaled = flat
+    flat_frame_correction(img, fl)
+    mos = img.sensor_scaled
+    assert np.isnan(mos[20:26, 30:38]).all() and np.isfinite(mos[50, 60])
+    for q, stages in ((QualityDemosaic.Draft, 0), (QualityDemosaic.Fast, 0), (QualityDemosaic.Best, 0)):
+        dem = RawRggbBayerData(mos, wbobj, 10.0, 1.0).demosaic(q, stages)
+        qi = {QualityDemosaic.Draft: 0, QualityDemosaic.Fast: 1, QualityDemosaic.Best: 2}[q]
+        ref_raw = [orc.demosaic_draft, orc.demosaic_eag, lambda b, w: orc.demosaic_ahd(b, w, M, False, 0)][qi](mos, wb)
+        assert _same(dem.image, ref_raw), q
+        srgb = lin_srgb_to_srgb(dem.to_lin_srgb())
+        assert _same(srgb, orc.pipeline_srgb(mos, wb, M, qi, False, 0, False)), q
+        assert np.isnan(srgb).any()
+
+
+def test_non_finite_pointwise_and_fusion(orc):
+    """clip_rgb / cam_to_lin_srgb / the sRGB curves / wb on NaN and Inf (transform.py:6-19,52-53,89-111); raw HDR fusion."""
+    import torch
+    from pysp_amd.colorize.transform import clip_rgb, lin_srgb_to_srgb, srgb_to_lin_srgb
+    from pysp_amd.pipeline import DevicePipeline
+    wb, M = _wbM(orc)
+    rng = np.random.default_rng(3)
+    px = (rng.random((33, 47, 3), dtype=np.float32) * np.float32(1.6) - np.float32(0.3)).astype(np.float32)
+    px[0, 0] = [np.nan, 0.5, 0.2]; px[0, 1] = [0.1, np.inf, 0.2]; px[0, 2] = [0.3, 0.4, -np.inf]; px[1, 1] = [np.nan, np.nan, np.nan]; px[2, 2] = [np.inf, -np.inf, np.nan]
+    want_clip = np.clip(px, 0, 1)
+    assert _same(clip_rgb(px), want_clip) and np.isnan(clip_rgb(px)[0, 0, 0])
+    assert _same(lin_srgb_to_srgb(px), orc.lin_srgb_to_srgb(px)) and _same(srgb_to_lin_srgb(px), orc.srgb_to_lin_srgb(px))
+    assert np.isnan(lin_srgb_to_srgb(px)[0, 0, 0]) and lin_srgb_to_srgb(px)[0, 1, 1] == 1.0 and lin_srgb_to_srgb(px)[0, 2, 2] == 0.0
+    from pysp_amd import _lib
+    L, ctx = _lib.lib(), _lib.default_context()
+    for clip in (1, 0):
+        out = np.empty_like(px)
+        _lib.check(L.pysp_cam_to_rgb_f32(ctx.handle, _lib.ptr(px), px.size // 3, _lib.mat9(M), clip, _lib.ptr(out)))
+        assert _same(out, orc.cam_to_rgb(px, M, bool(clip))), clip
+    # raw fusion: a NaN sample poisons its pixel's weight sum (raw_hdr.py:135-148 literally)
+    pipe = DevicePipeline(0)
+    H, W, K = 48, 64, 3
+    frames = [np.clip(rng.random((H, W), dtype=np.float32) * np.float32(2.0 ** -k), 0, 1) for k in range(K)]
+    frames[1][5, 7] = np.nan; frames[0][9, 9] = np.inf; frames[2][11, 3] = -np.inf
+    evs = [10.0, 11.0, 12.0]
+    fused, count, _, _ = pipe.fuse_raw([torch.from_numpy(f).cuda() for f in frames], evs, wb)
+    rf, rc = orc.fuse_raw(frames, evs, wb)[:2]
+    assert _same(fused.cpu().numpy(), rf) and np.array_equal(count.cpu().numpy(), rc) and np.isnan(rf[5, 7])
