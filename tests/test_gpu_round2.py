@@ -161,7 +161,7 @@ def test_non_finite_mosaic_matches_literal_oracle(orc, wbobj):
                     near |= np.roll(np.roll(np.pad(bad, 4), dy, 0), dx, 1)[4:-4, 4:-4]
             got = pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, hdr, 1).cpu().numpy()
             ref = orc.demosaic_ahd(bay, wb, M, hdr, 1)
-            assert near.mean() < 0.5 and np.array_equal(got[~near], ref[~near]), hdr
+            assert (~near).sum() > 1500 and np.array_equal(got[~near], ref[~near]), hdr
 
 
 def test_non_finite_from_the_products_own_flat_field(orc, wbobj):
