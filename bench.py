@@ -1,35 +1,46 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s of the fused AHD demosaic + cam->sRGB path on synthetic 24 MP RGGB frames.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--workload ...] [--backend nccl|gloo]
 
-One "step" = one frame of BASELINE.json configs[1]: 6000x4000 float32 RGGB mosaic, resident in HBM,
--> QualityDemosaic.Best (AHD, postprocess_steps=1) -> to_lin_srgb (clip + float64 CCM) ->
-lin_srgb_to_srgb -> (H,W,3) float32 sRGB, resident in HBM; two kernels, one C-ABI call
-(pysp_pipeline_srgb_dev).  Frames are independent, so ranks shard frames with no data-path
-collective (weak scaling); the shared WB/CCM parameter block is broadcast from rank 0 over RCCL
-once, before the timed region.  Prints ONE JSON line on rank 0.
+`--gpus N` with N > 1 may be given either under an external launcher (the driver's
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: RANK / WORLD_SIZE are in the environment) or
+bare (`python bench.py --gpus N`): then this process starts that very launcher as a child BEFORE anything touches the GPU,
+waits for it and exits with its code -- the parent never initialises HIP.  One rank per GPU; rank 0 prints ONE JSON line.
+
+Default workload (`ahd24`) = BASELINE.json configs[1]: one step = one 6000x4000 float32 RGGB mosaic, resident in HBM, ->
+QualityDemosaic.Best (AHD, postprocess_steps=1) -> to_lin_srgb (clip + float64 CCM) -> lin_srgb_to_srgb -> (H,W,3) float32
+sRGB, resident in HBM; two kernels, one C-ABI call.  Frames are independent, so ranks shard frames with no data-path
+collective (weak scaling); rank 0 owns the WB/CCM parameter block and broadcasts it (RCCL over xGMI) once per batch of
+resident frames INSIDE the timed region.
+
+Multi-GPU workloads of BASELINE.json:
+    cfg3  configs[2]: 64 distinct 24 MP frames per 8 GPUs = 8 frames per rank per step, EAG + WB + 3x3 CCM (tail 1), one
+          parameter broadcast per batch inside the timed region, one batched C-ABI call per rank; weak scaling.
+    cfg5  configs[4]: ONE 100 MP frame per step, AHD (postprocess_stages=3) + WarpRectilinear, cut into N horizontal
+          bands (pysp_amd.multi_gpu): demosaic of the band -> all-gather of the warp's source-row bounds -> point-to-point
+          exchange of exactly those rows (RCCL send/recv) -> warp of the band; strong scaling; per-phase times reported.
+`--backend gloo` rehearses the N > 1 paths with host-staged collectives (any number of ranks may share one GPU).
 """
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch  # first: keeps a single HIP runtime in the process (see pysp_amd/_lib.py)
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MAX_CLOCK_HZ = 2.4e9           # MI355X_MICROARCH.md chip table; the VALU bound below is quoted at this clock
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs, one wave64 VALU instruction issues over >= 2 cycles on a SIMD
 ALG_BYTES_PER_PX = 16          # the fused path: 4 B mosaic read + 12 B RGB written
 # per kernel: the select kernel reads the mosaic and writes RGB, a median stage reads and writes RGB
-KERNEL_ALG_BYTES_PER_PX = {"k_ahd_select": 16, "k_ahd_median_stage": 24}
+KERNEL_ALG_BYTES_PER_PX = {"k_ahd_select": 16, "k_ahd_median_stage": 24, "k_eag": 16, "k_draft": 16, "k_warp_remap": 24}
 
 WORKLOADS = {
     # name: (H, W, quality, stages, description[, tail])   tail: 2 = to_lin_srgb + lin_srgb_to_srgb (default), 1 = to_lin_srgb only
@@ -42,77 +53,155 @@ WORKLOADS = {
     # secondary kernels (BASELINE configs 4 and 5), reported with their own algorithmic bytes
     "fuse45": (5464, 8192, -1, 0, "raw_hdr fuse_exposures_to_raw, 7 x 45MP exposures -> HDR mosaic + count (36 B per output px)"),
     "warp100": (8736, 11648, -2, 0, "100MP RGB, DNG WarpRectilinear per-channel Lanczos-4 remap (24 B/px)"),
+    # whole BASELINE configs across the GPUs of a node
+    "cfg3": (4000, 6000, 1, 0, "BASELINE config 3: batch of 64 x 24MP frames per 8 GPUs (8 frames per rank per step), EAG + WB + 3x3 CCM, frame-sharded, RCCL parameter broadcast per batch", 1),
+    "cfg5": (8736, 11648, 2, 3, "BASELINE config 5: one 100MP frame per step, AHD (postprocess_stages=3) + WarpRectilinear, horizontal bands over the GPUs, RCCL exchange of the warp's source rows", 0),
 }
+WARP_COEFFS = [[1.0, 0.01, 0.002, 0.0, 0.0, 0.0], [1.0, 0.0, 0.002, 0.0, 0.0, 0.0], [1.0, -0.01, 0.002, 0.0, 0.0, 0.0]]
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled")
+    ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled (cfg3: frames per rank per step, default 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (contexts) the frames of a rank are cycled over.  With 2, consecutive (independent) frames overlap: the next "
-                         "frame's first kernel fills the drain of the previous frame's last one, +2 % throughput, but concurrent kernels "
+                         "frame's first kernel fills the drain of the previous frame's last one, +2 %% throughput, but concurrent kernels "
                          "stretch each other, so per-kernel durations (rocprofv3's, too) stop meaning anything; the default keeps them clean")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the N > 1 path on one GPU)")
-    args = ap.parse_args()
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo rehearses the N > 1 path with host-staged collectives, ranks may share a GPU)")
+    ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
+    ap.add_argument("--settle", type=float, default=0.4,
+                    help="seconds of untimed steps run BEFORE the W warmup steps so that the clocks have reached their loaded state when a short "
+                         "(e.g. 20-step) timed region starts; 0 disables.  The timed region is exactly K steps either way")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: become the launcher's parent.  Nothing in this process has touched the GPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main() -> None:
+    args = parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch  # first: keeps a single HIP runtime in the process (see pysp_amd/_lib.py)
+    import numpy as np
+    import ctypes
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     dist = None
     n_dev = max(1, torch.cuda.device_count())
-    dev_index = local_rank % n_dev                 # one rank per GPU; the modulo only matters for a gloo rehearsal on one GPU
-    if world > 1:
+    dev_index = local_rank % n_dev                 # one rank per GPU; the modulo only matters for a gloo rehearsal on fewer GPUs
+    torch.cuda.set_device(dev_index)
+    if world_env > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend="gloo")
-    else:
-        torch.cuda.set_device(dev_index)
+    world = dist.get_world_size() if dist is not None else 1          # the world size actually observed, reported as n_gpus
     dev = torch.device("cuda", dev_index)
-    coll_dev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")
+    via_host = dist is not None and args.backend == "gloo"
+    coll_dev = torch.device("cpu") if via_host else dev
 
     from pysp_amd import _lib
     from pysp_amd.colorize.transform import final_matrix
+    from pysp_amd.multi_gpu import PARAM_DOUBLES, pack_params, unpack_params
     from pysp_amd.synth import default_wb, rggb_frame
 
     H, W, quality, stages, desc = WORKLOADS[args.workload][:5]
     tail = WORKLOADS[args.workload][5] if len(WORKLOADS[args.workload]) > 5 else 2
     mp_per_frame = H * W / 1e6
 
-    # ---- shared parameters: rank 0 owns them, everyone receives them over RCCL/xGMI (once per batch)
-    from pysp_amd.multi_gpu import broadcast_params
-    if rank == 0:
-        wbobj = default_wb()
-        wb_np, M_np = broadcast_params(wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix()), src=0, device=coll_dev)
-    else:
-        wb_np, M_np = broadcast_params(np.zeros(3, np.float32), np.zeros((3, 3)), src=0, device=coll_dev)
-    p = np.concatenate([wb_np.astype(np.float64), M_np.reshape(-1)])
-    wb = _lib.wb3(wb_np)
-    M = _lib.mat9(M_np)
+    # ---- shared parameters: rank 0 owns the camera metadata; everyone receives the 96-byte block over RCCL/xGMI.
+    # `share_params` is what runs inside the timed region, once per batch.
+    wbobj = default_wb() if rank == 0 else None
+    block0 = pack_params(wbobj.get_reciprocal_multipliers(), final_matrix(wbobj.get_matrix())) if rank == 0 else np.zeros(PARAM_DOUBLES)
+    pbuf = torch.zeros(PARAM_DOUBLES, dtype=torch.float64, device=coll_dev)
 
-    n_streams = max(1, args.streams)
+    def share_params():
+        if dist is None:
+            return unpack_params(block0)
+        if rank == 0:
+            pbuf.copy_(torch.from_numpy(block0))
+        dist.broadcast(pbuf, src=0)
+        return unpack_params(pbuf.cpu().numpy())             # the kernels take the block by value: one 96-byte read-back per batch
+
+    wb_np, M_np = share_params()
+    p = np.concatenate([wb_np.astype(np.float64), M_np.reshape(-1)])
+    state = {"wb": _lib.wb3(wb_np), "M": _lib.mat9(M_np), "wb_np": wb_np, "M_np": M_np}
+
+    def refresh_params():
+        w, m = share_params()
+        state.update(wb=_lib.wb3(w), M=_lib.mat9(m), wb_np=w, M_np=m)
+
+    n_streams = max(1, args.streams) if args.workload not in ("cfg3", "cfg5") else 1
     ctxs = [_lib.Context(dev_index) for _ in range(n_streams)]   # own HIP streams; kernels are timed with events on THOSE streams
     ctx = ctxs[0]
     L = _lib.lib()
     alg_bytes_per_px = ALG_BYTES_PER_PX
+    frames_per_step = 1
+    scaling = "weak"
+    phase_ms = None
+    extra_cfg = {}
+    kernel_ctx = ctx                                              # the context whose per-kernel event pairs are read
 
-    if quality >= 0:
+    if args.workload == "cfg3":
+        from pysp_amd.pipeline import DevicePipeline
+        pipe = DevicePipeline(dev_index)
+        kernel_ctx = pipe.ctx
+        nf = args.frames if args.frames != 3 else 8
+        frames_per_step = nf
+        frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * nf + i)).to(dev) for i in range(nf)]      # frame i of rank r: seed 1000 + r*nf + i
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(nf)]
+        extra_cfg = {"frames_per_rank_per_step": nf, "frames_per_step_total": nf * world, "param_broadcast": "once per step (batch), inside the timed region"}
+
+        def step(i: int) -> None:
+            refresh_params()
+            pipe.batch(frames, state["wb_np"], state["M_np"], quality, False, 0, tail, outs)
+    elif args.workload == "cfg5":
+        from pysp_amd.multi_gpu import PHASES, BandPlan, demosaic_warp_banded_dev
+        from pysp_amd.pipeline import DevicePipeline
+        pipe = DevicePipeline(dev_index)
+        kernel_ctx = pipe.ctx
+        scaling = "strong"
+        plan = BandPlan(H, W, world, rank, stages)
+        bayer = rggb_frame(H, W, 1000)                            # every rank derives the same frame, keeps only its band + halo
+        sub = torch.from_numpy(np.ascontiguousarray(bayer[plan.r0:plan.r1])).to(dev)
+        del bayer
+        frames = [sub]
+        full = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        outb = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        coeffs = np.array(WARP_COEFFS)
+        marks = []
+        extra_cfg = {"bands": world, "band_rows": plan.y1 - plan.y0, "halo_rows": plan.y0 - plan.r0 if rank else plan.r1 - plan.y1,
+                     "exchange": args.exchange, "collective": "RCCL all_gather of row bounds + batched send/recv of the needed rows" if not via_host else "gloo, host staged (rehearsal)"}
+
+        def step(i: int, mark=None) -> None:
+            demosaic_warp_banded_dev(pipe, sub, plan, state["wb_np"], state["M_np"], coeffs, (0.5, 0.5), 1.0, None, args.exchange, via_host, full, outb, mark)
+    elif quality >= 0:
         # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
         frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
         outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(n_streams)]
+        share_every = len(frames) if dist is not None else 0       # one parameter broadcast per batch of resident frames, inside the timed region
+        if share_every:
+            extra_cfg = {"param_broadcast": f"once per {share_every} steps (one batch of resident frames), inside the timed region"}
 
         if args.workload.endswith("u16"):
             # 14-bit sensor counts, black 512, saturation 15871 per site (normalization.py:4-24 runs inside the tile loaders)
@@ -124,13 +213,15 @@ def main() -> None:
             def step(i: int) -> None:
                 f = frames[i % len(frames)]
                 s = i % n_streams
-                _lib.check(L.pysp_pipeline_u16_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, black, sat, wb, M, quality, 0, stages, tail,
+                _lib.check(L.pysp_pipeline_u16_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, black, sat, state["wb"], state["M"], quality, 0, stages, tail,
                                                    ctypes.c_void_p(outs[s].data_ptr())))
         else:
             def step(i: int) -> None:
+                if share_every and i % share_every == 0:
+                    refresh_params()
                 f = frames[i % len(frames)]
                 s = i % n_streams                       # frame i runs on stream s, writing that stream's output buffer
-                _lib.check(L.pysp_pipeline_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, wb, M, quality, 0, stages, tail,
+                _lib.check(L.pysp_pipeline_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, state["wb"], state["M"], quality, 0, stages, tail,
                                                ctypes.c_void_p(outs[s].data_ptr())))
     elif quality == -1:
         K = 7
@@ -153,7 +244,7 @@ def main() -> None:
     else:
         frames = [torch.rand((H, W, 3), dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(1000 + rank))]
         out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-        coeffs = np.array([[1.0, 0.01, 0.002, 0.0, 0.0, 0.0], [1.0, 0.0, 0.002, 0.0, 0.0, 0.0], [1.0, -0.01, 0.002, 0.0, 0.0, 0.0]])
+        coeffs = np.array(WARP_COEFFS)
         cptr = coeffs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         alg_bytes_per_px = 24
 
@@ -169,13 +260,27 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
 
+    # ---- untimed: bring the clocks to their loaded state (a 20-step timed region is 15 ms of GPU time, shorter than the ramp),
+    # then the W warmup steps the caller asked for
+    settle_steps = 0
+    if args.settle > 0 and dist is None:                          # N = 1 only: at N > 1 every rank would have to agree on a count
+        t_end = time.perf_counter() + args.settle
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step(settle_steps); settle_steps += 1
+            ctx.sync(); torch.cuda.synchronize()
+    elif args.settle > 0:
+        settle_steps = max(1, int(round(args.settle / 1e-3 / max(1.0, mp_per_frame * frames_per_step / 30.0))))   # ~1 ms per 30 MP: same count on every rank
+        for i in range(settle_steps):
+            step(i)
     for i in range(args.warmup):
         step(i)
     fence()
 
-    # ---- timed region: exactly K steps, nothing but the kernels on the stream (no event records inside)
+    # ---- timed region: exactly K steps, nothing but the path's own work on the stream (no event records inside)
     for c in ctxs:
         c.set_kernel_timing(0)
+    kernel_ctx.set_kernel_timing(0)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -192,17 +297,48 @@ def main() -> None:
         elapsed = float(t.item())
 
     # ---- per-kernel durations: the same steps again, each kernel bracketed by HIP events on the launch
-    # stream (recording them inside the timed region would add ~50 us of event traffic to every 1.1 ms step)
+    # stream (recording them inside the timed region would add ~50 us of event traffic to every step)
     # (one stream only here, so that a kernel's duration is not stretched by a neighbour sharing the CUs)
     fence()
-    ctx.set_kernel_timing(2)
     samples: dict = {}
-    for i in range(min(16, max(4, args.steps))):
-        step(i * n_streams)
-        for name, ms in ctx.kernel_times():
-            samples.setdefault(name, []).append(ms)
-    ctx.set_kernel_timing(1)
+    if args.workload == "cfg5":
+        # per phase: events on the (single) stream everything is enqueued on; per kernel: the library's own event pairs
+        acc = np.zeros(len(PHASES))
+        reps = min(8, max(2, args.steps))
+        for i in range(reps):                                # pass A: phase boundaries
+            evs = []
+
+            def mark(k):
+                e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+            step(i, mark)
+            torch.cuda.synchronize()
+            acc += [evs[k].elapsed_time(evs[k + 1]) for k in range(len(PHASES))]
+            if dist is not None:
+                dist.barrier()
+        pipe.ctx.set_kernel_timing(2)
+        for i in range(min(4, reps)):                        # pass B: kernels (reading a call's event pairs waits for them: kept out of pass A)
+            def mark(k):
+                if k in (1, 4):                              # right after the demosaic call / the warp call
+                    for name, ms in pipe.ctx.kernel_times():
+                        samples.setdefault(name, []).append(ms)
+            step(i, mark)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+        pipe.ctx.set_kernel_timing(1)
+        ph = torch.tensor(acc / reps, dtype=torch.float64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        phase_ms = {n: round(float(v), 4) for n, v in zip(PHASES, ph.cpu().tolist())}
+    else:
+        kernel_ctx.set_kernel_timing(2)
+        for i in range(min(16, max(4, args.steps))):
+            step(i * n_streams)
+            for name, ms in kernel_ctx.kernel_times():
+                samples.setdefault(name, []).append(ms)
+        kernel_ctx.set_kernel_timing(1)
     per_kernel = {k: float(np.mean(v)) for k, v in samples.items()}
+    launches = {k: len(v) for k, v in samples.items()}
 
     if rank != 0:
         if dist is not None:
@@ -210,38 +346,68 @@ def main() -> None:
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps * mp_per_frame / elapsed
-    dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
-    alg_bytes = KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px) * H * W      # of the dominant kernel's own launch
+    units_per_step = mp_per_frame * frames_per_step * (1 if scaling == "strong" else world)
+    value = args.steps * units_per_step / elapsed
+    # dominant kernel = the one the stream spends most time in (launch count x mean duration: a median stage runs `stages` times)
+    tot = {k: per_kernel[k] * launches[k] for k in per_kernel}
+    dom = max(tot, key=tot.get) if tot else None
     roofline = None
-    traffic = None
-    try:   # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside the benchmark itself)
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tj = json.load(f)
-        if args.workload == "ahd24" and dom in tj:
-            traffic = tj[dom]
-    except (OSError, ValueError):
-        pass
     if dom:
+        px_per_launch = H * W
+        if args.workload == "cfg5" and dom != "k_warp_remap":
+            px_per_launch = (plan.r1 - plan.r0) * W               # a band kernel processes the band plus its halo rows
+        elif args.workload == "cfg5":
+            px_per_launch = (plan.y1 - plan.y0) * W
+        kb = KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px)
+        alg_bytes = kb * px_per_launch                            # of the dominant kernel's own launch
+        traffic, valu = None, None
+        try:   # HBM bytes and VALU instructions per launch from the PMC passes (rocprofv3 cannot run inside the benchmark itself)
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            ent = tj.get(args.workload, tj if args.workload == "ahd24" else {}).get(dom)
+            if isinstance(ent, dict):
+                traffic = ent.get("hbm_bytes")
+                if ent.get("valu_insts"):
+                    insts = float(ent["valu_insts"])
+                    cyc = per_kernel[dom] * 1e-3 * MAX_CLOCK_HZ * N_SIMD / insts
+                    valu = {"insts_per_px": round(insts * 64 / px_per_launch, 1), "wave_insts_per_launch": insts, "cycles_per_inst": round(cyc, 3),
+                            "frac_of_2cycle_issue": round(2.0 / cyc, 4), "clock_hz": MAX_CLOCK_HZ,
+                            "source": ent.get("source", "profiles/traffic.json")}
+            elif ent is not None:
+                traffic = ent
+        except (OSError, ValueError, AttributeError):
+            pass
         achieved = alg_bytes / (per_kernel[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(per_kernel[dom], 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
-                    "alg_bytes_per_px": KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px),
-                    "pipeline_frac": round(alg_bytes_per_px * H * W / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "note": "AHD is VALU-issue bound (725 + 543 wave-level instructions per pixel in the two kernels vs 16 B/px for the path, one every 3.0 / 3.3 cycles per SIMD, profiles/r1_v19_pmc_summary.csv); pipeline_frac is the whole two-kernel step against the path's 16 B/px; the HBM fraction is reported as required, not expected to approach 1"}
+                    "alg_bytes_per_px": kb,
+                    "pipeline_frac": round(alg_bytes_per_px * units_per_step * 1e6 / (ms_per_step * 1e-3) / 1e9 / (world * HBM_PEAK_GBS), 5),
+                    "valu": valu,
+                    "note": "pipeline_frac = the path's algorithmic bytes of one whole step over the step time and the aggregate HBM peak of the GPUs used; valu = wave-level VALU instructions per launch (PMC, profiles/) "
+                            "spread over the chip's 1024 SIMDs at 2.4 GHz against the 2-cycle issue rate of a wave64 instruction: the AHD kernels are bound by VALU issue, not by HBM"}
 
     cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline and quality >= 0:
+    if world == 1 and not args.no_cpu_baseline and quality >= 0 and args.workload != "cfg5":
         try:
             from oracle import oracle
             Mo = p[3:].reshape(3, 3)
             done, dt = 0, 0.0
             for f in frames:                         # bounded sample: whole resident frames until about 10 s of CPU work are spent
                 sample = np.ascontiguousarray(f.cpu().numpy())
+                if sample.dtype != np.float32:
+                    sample = oracle.bayer_normalize(sample.view(np.uint16), [512.0] * 4, [15871.0] * 4)
                 t1 = time.perf_counter()
-                oracle.pipeline_srgb(sample, p[:3].astype(np.float32), Mo, quality, False, stages, False)
+                if tail == 2:
+                    oracle.pipeline_srgb(sample, p[:3].astype(np.float32), Mo, quality, False, stages, False)
+                else:
+                    if quality < 2:
+                        raw = [oracle.demosaic_draft, oracle.demosaic_eag][quality](sample, p[:3].astype(np.float32))
+                    else:
+                        raw = oracle.demosaic_ahd(sample, p[:3].astype(np.float32), Mo, False, stages)
+                    if tail == 1:
+                        oracle.cam_to_rgb(raw, Mo, True)
                 dt += time.perf_counter() - t1
                 done += 1
                 if dt > 10.0:
@@ -251,14 +417,21 @@ def main() -> None:
         except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
             cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc}"}
 
+    cfg = {"workload": desc, "H": H, "W": W, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
+           "backend": ("rccl" if args.backend == "nccl" else "gloo") if dist is not None else None,
+           "untimed_settle_steps": settle_steps,
+           "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"
+                        else "frame-parallel, no data-path collective; WB/CCM block broadcast from rank 0 (RCCL) per batch")}
+    cfg.update(extra_cfg)
     line = {
         "metric": "megapixels/sec AHD debayer+cam->sRGB, 24MP RGGB" if args.workload == "ahd24" else f"megapixels/sec {args.workload}",
         "value": round(value, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": desc, "H": H, "W": W, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams, "sharding": "frame-parallel, no data-path collective; WB/CCM broadcast once over RCCL"},
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "config": cfg,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
+    if phase_ms is not None:
+        line["phases_ms"] = phase_ms
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

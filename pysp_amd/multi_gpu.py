@@ -146,11 +146,61 @@ def ahd_halo_rows(stages: int) -> int:
     return 8 + 4 * max(0, int(stages))
 
 
-def _settle(pipe, via_host: bool) -> None:
-    """DevicePipeline enqueues on torch's current stream, so kernels, tensor copies and RCCL collectives are already
-    ordered.  Only the host-staged rehearsal path (gloo) reads device data from the host and needs it finished."""
-    if via_host:
-        pipe.sync()
+PHASES = ("demosaic", "bound_allgather", "row_exchange", "warp")
+
+
+class BandPlan:
+    """Band geometry of one frame cut over `world` ranks for AHD(stages) + WarpRectilinear (BASELINE config 5)."""
+
+    def __init__(self, H: int, W: int, world: int, rank: int, stages: int):
+        bands4 = band_ranges(H, world, ahd_halo_rows(stages))
+        if len(bands4) != world:
+            raise ValueError(f"a {H}-row frame cannot be cut into {world} bands")
+        self.H, self.W, self.world, self.rank, self.stages = H, W, world, rank, stages
+        self.bands = [(b[0], b[1]) for b in bands4]
+        self.y0, self.y1, self.r0, self.r1 = bands4[rank]
+
+
+def demosaic_warp_banded_dev(pipe, sub, plan: BandPlan, wb, M, coeffs, centre, scale: float = 1.0, group=None, exchange: str = "needed",
+                             via_host: bool = False, full=None, out=None, mark=None):
+    """Device-resident core of `demosaic_warp_banded`: `sub` holds mosaic rows [plan.r0, plan.r1) of the frame (the band
+    plus its stencil halo) on the device.  `full` / `out` are optional reusable whole-frame (H,W,3) buffers.  `mark(i)`, if
+    given, is called at the start of phase PHASES[i] and once more (i = 4) at the end (the benchmark records events there).
+    Everything is enqueued on torch's current stream; the only host waits are the two the algorithm itself needs (the row
+    bounds come back from the device, and the all-gathered bounds are read to build the exchange plan)."""
+    from . import _lib
+    torch = pipe.torch
+    H, W, world, rank = plan.H, plan.W, plan.world, plan.rank
+    y0, y1, r0 = plan.y0, plan.y1, plan.r0
+    mark = mark or (lambda i: None)
+    mark(0)
+    rgb = pipe.demosaic(sub, wb, M, _lib.QUALITY_BEST, False, plan.stages)
+    full = torch.empty((H, W, 3), dtype=torch.float32, device=pipe.device) if full is None else full
+    full[y0:y1].copy_(rgb[y0 - r0:y1 - r0])
+    del rgb
+    mark(1)
+    if world > 1:
+        import torch.distributed as dist
+        if exchange == "needed":
+            s0, s1 = pipe.warp_source_rows(H, W, coeffs, centre, y0, y1, scale)
+            mine = torch.tensor([s0, s1], dtype=torch.int64, device="cpu" if via_host else pipe.device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            needs = [(int(t[0]), int(t[1])) for t in every]
+            mark(2)
+            exchange_rows(full, plan_row_exchange(plan.bands, needs), rank, group, via_host)
+        elif exchange == "allgather":
+            mark(2)
+            allgather_bands(full, plan.bands, rank, group, via_host)
+        else:
+            raise ValueError("exchange must be 'needed' or 'allgather'")
+    else:
+        mark(2)
+    mark(3)
+    out = torch.empty_like(full) if out is None else out
+    pipe.warp_rows(full, coeffs, centre, y0, y1, out, scale)
+    mark(4)
+    return out[y0:y1]
 
 
 def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0,
@@ -159,34 +209,10 @@ def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, st
     the same band (chan_distortion_corr.py:86-97 after debayer/ahd.py).  `pipe` is this rank's DevicePipeline.
     Returns (y0, y1, band) with band = rows [y0, y1) of the warped (H,W,3) frame on the device; the rows are identical
     to the same rows of `pipe.demosaic_warp` on the whole frame."""
-    from . import _lib
     torch = pipe.torch
     H, W = bayer_host.shape
-    bands4 = band_ranges(H, world, ahd_halo_rows(stages))
-    if len(bands4) != world:
-        raise ValueError(f"a {H}-row frame cannot be cut into {world} bands")
-    bands = [(b[0], b[1]) for b in bands4]
-    y0, y1, r0, r1 = bands4[rank]
-    sub = torch.from_numpy(np.ascontiguousarray(bayer_host[r0:r1])).to(pipe.device)
-    rgb = pipe.demosaic(sub, wb, M, _lib.QUALITY_BEST, False, stages)
-    full = torch.empty((H, W, 3), dtype=torch.float32, device=pipe.device)
-    full[y0:y1].copy_(rgb[y0 - r0:y1 - r0])
-    del rgb, sub
-    if world > 1:
-        import torch.distributed as dist
-        _settle(pipe, via_host)
-        if exchange == "needed":
-            s0, s1 = pipe.warp_source_rows(H, W, coeffs, centre, y0, y1, scale)
-            mine = torch.tensor([s0, s1], dtype=torch.int64, device="cpu" if via_host else pipe.device)
-            every = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(every, mine, group=group)
-            needs = [(int(t[0]), int(t[1])) for t in every]
-            exchange_rows(full, plan_row_exchange(bands, needs), rank, group, via_host)
-        elif exchange == "allgather":
-            allgather_bands(full, bands, rank, group, via_host)
-        else:
-            raise ValueError("exchange must be 'needed' or 'allgather'")
-    out = torch.empty_like(full)
-    pipe.warp_rows(full, coeffs, centre, y0, y1, out, scale)
+    plan = BandPlan(H, W, world, rank, stages)
+    sub = torch.from_numpy(np.ascontiguousarray(bayer_host[plan.r0:plan.r1])).to(pipe.device)
+    band = demosaic_warp_banded_dev(pipe, sub, plan, wb, M, coeffs, centre, scale, group, exchange, via_host)
     pipe.sync()
-    return y0, y1, out[y0:y1]
+    return plan.y0, plan.y1, band

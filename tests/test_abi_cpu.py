@@ -199,3 +199,28 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
     assert len(hot) == 9                                             # eight select variants (tiny / uint16 / HDR metric) and the median stage
     for v in hot:                                                    # five 256-thread workgroups per CU: <= 96 VGPRs and <= 32 KB of LDS each
         assert v["vgpr_count"] <= 96 and v["group_segment_fixed_size"] <= 32768, v
+
+
+def test_bench_bare_multi_gpu_invocation_becomes_a_launcher(monkeypatch):
+    """`python bench.py --gpus 4` without RANK/WORLD_SIZE: the process re-invokes itself under torch.distributed.run (one rank
+    per GPU, rendezvous on 127.0.0.1) before importing torch or touching the GPU, and exits with the child's code."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--workload", "cfg3", "--steps", "5"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    had_torch = "torch" in sys.modules
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--workload", "cfg3", "--steps", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert had_torch or "torch" not in sys.modules            # the parent did not even import torch

@@ -223,3 +223,45 @@ def test_non_finite_pointwise_and_fusion(orc):
     fused, count, _, _ = pipe.fuse_raw([torch.from_numpy(f).cuda() for f in frames], evs, wb)
     rf, rc = orc.fuse_raw(frames, evs, wb)[:2]
     assert _same(fused.cpu().numpy(), rf) and np.array_equal(count.cpu().numpy(), rc) and np.isnan(rf[5, 7])
+
+
+# ---- bench.py starts its own ranks; configs 3 and 5 are bench workloads ---------------------
+def _bench(*argv, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_cfg5_banded():
+    """`python bench.py --gpus 2 --backend gloo --workload cfg5` as typed (no external launcher): two ranks share the box's
+    one GPU, 100 MP AHD(3) + warp in two bands with the row exchange, ONE JSON line, n_gpus = the observed world size."""
+    line = _bench("--gpus", "2", "--backend", "gloo", "--workload", "cfg5", "--steps", "2", "--warmup", "1", "--settle", "0")
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["bands"] == 2 and line["config"]["backend"] == "gloo"
+    assert set(line["phases_ms"]) == {"demosaic", "bound_allgather", "row_exchange", "warp"} and line["phases_ms"]["demosaic"] > 0
+    assert line["value"] > 0 and line["roofline"]["kernel"] in ("k_ahd_median_stage", "k_ahd_select", "k_warp_remap")
+
+
+def test_bench_cfg3_batch_two_ranks_and_single():
+    line = _bench("--gpus", "2", "--backend", "gloo", "--workload", "cfg3", "--frames", "2", "--steps", "3", "--warmup", "1", "--settle", "0")
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_per_step_total"] == 4
+    assert line["roofline"]["kernel"] == "k_eag" and line["cpu_baseline"] is None
+    one = _bench("--workload", "cfg3", "--frames", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert one["n_gpus"] == 1 and one["config"]["frames_per_step_total"] == 2 and one["value"] > 0
+
+
+def test_bench_default_line_contract():
+    """The driver's own command shape (N = 1, short run): metric, config, roofline with the VALU bound, cpu_baseline."""
+    line = _bench("--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert line["metric"].startswith("megapixels/sec AHD debayer+cam->sRGB") and line["unit"] == "MP/s" and line["dtype"] == "f32"
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["vs_baseline"] is None
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"]
+    assert r["valu"] and 0 < r["valu"]["frac_of_2cycle_issue"] <= 1.0 and r["valu"]["insts_per_px"] > 100
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
