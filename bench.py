@@ -363,19 +363,20 @@ def main() -> None:
         traffic, valu = None, None
         try:   # HBM bytes and VALU instructions per launch from the PMC passes (rocprofv3 cannot run inside the benchmark itself)
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                tj = json.load(f)
-            ent = tj.get(args.workload, tj if args.workload == "ahd24" else {}).get(dom)
-            if isinstance(ent, dict):
-                traffic = ent.get("hbm_bytes")
-                if ent.get("valu_insts"):
+                tj = json.load(f).get(args.workload, {})
+            traffic = tj.get(dom, {}).get("hbm_bytes")
+            per = {}
+            for k, ent in tj.items():                             # every kernel of the step that has a PMC record
+                if k in per_kernel and ent.get("valu_insts"):
                     insts = float(ent["valu_insts"])
-                    cyc = per_kernel[dom] * 1e-3 * MAX_CLOCK_HZ * N_SIMD / insts
-                    valu = {"insts_per_px": round(insts * 64 / px_per_launch, 1), "wave_insts_per_launch": insts, "cycles_per_inst": round(cyc, 3),
-                            "frac_of_2cycle_issue": round(2.0 / cyc, 4), "clock_hz": MAX_CLOCK_HZ,
-                            "source": ent.get("source", "profiles/traffic.json")}
-            elif ent is not None:
-                traffic = ent
-        except (OSError, ValueError, AttributeError):
+                    cyc = per_kernel[k] * 1e-3 * MAX_CLOCK_HZ * N_SIMD / insts
+                    per[k] = {"insts_per_px": round(insts * 64 / ent.get("px", px_per_launch), 1), "wave_insts_per_launch": insts,
+                              "cycles_per_inst": round(cyc, 3), "frac_of_2cycle_issue": round(2.0 / cyc, 4), "source": ent.get("source")}
+            if dom in per:
+                ideal_ms = sum(2.0 * float(tj[k]["valu_insts"]) * launches[k] / (len(samples[dom]) or 1) for k in per) / N_SIMD / MAX_CLOCK_HZ * 1e3
+                valu = dict(per[dom], clock_hz=MAX_CLOCK_HZ, all_kernels=per,
+                            step_ms_at_2cycle_issue=round(ideal_ms, 4), step_frac_of_2cycle_issue=round(ideal_ms / (ms_per_step / frames_per_step), 4))
+        except (OSError, ValueError, AttributeError, KeyError, TypeError):
             pass
         achieved = alg_bytes / (per_kernel[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
