@@ -301,6 +301,7 @@ def main() -> None:
     # (one stream only here, so that a kernel's duration is not stretched by a neighbour sharing the CUs)
     fence()
     samples: dict = {}
+    sample_steps = 0
     if args.workload == "cfg5":
         # per phase: events on the (single) stream everything is enqueued on; per kernel: the library's own event pairs
         acc = np.zeros(len(PHASES))
@@ -316,7 +317,8 @@ def main() -> None:
             if dist is not None:
                 dist.barrier()
         pipe.ctx.set_kernel_timing(2)
-        for i in range(min(4, reps)):                        # pass B: kernels (reading a call's event pairs waits for them: kept out of pass A)
+        sample_steps = min(4, reps)
+        for i in range(sample_steps):                        # pass B: kernels (reading a call's event pairs waits for them: kept out of pass A)
             def mark(k):
                 if k in (1, 4):                              # right after the demosaic call / the warp call
                     for name, ms in pipe.ctx.kernel_times():
@@ -332,7 +334,8 @@ def main() -> None:
         phase_ms = {n: round(float(v), 4) for n, v in zip(PHASES, ph.cpu().tolist())}
     else:
         kernel_ctx.set_kernel_timing(2)
-        for i in range(min(16, max(4, args.steps))):
+        sample_steps = min(16, max(4, args.steps))
+        for i in range(sample_steps):
             step(i * n_streams)
             for name, ms in kernel_ctx.kernel_times():
                 samples.setdefault(name, []).append(ms)
@@ -373,7 +376,7 @@ def main() -> None:
                     per[k] = {"insts_per_px": round(insts * 64 / ent.get("px", px_per_launch), 1), "wave_insts_per_launch": insts,
                               "cycles_per_inst": round(cyc, 3), "frac_of_2cycle_issue": round(2.0 / cyc, 4), "source": ent.get("source")}
             if dom in per:
-                ideal_ms = sum(2.0 * float(tj[k]["valu_insts"]) * launches[k] / (len(samples[dom]) or 1) for k in per) / N_SIMD / MAX_CLOCK_HZ * 1e3
+                ideal_ms = sum(2.0 * float(tj[k]["valu_insts"]) * launches[k] / max(1, sample_steps) for k in per) / N_SIMD / MAX_CLOCK_HZ * 1e3
                 valu = dict(per[dom], clock_hz=MAX_CLOCK_HZ, all_kernels=per,
                             step_ms_at_2cycle_issue=round(ideal_ms, 4), step_frac_of_2cycle_issue=round(ideal_ms / (ms_per_step / frames_per_step), 4))
         except (OSError, ValueError, AttributeError, KeyError, TypeError):

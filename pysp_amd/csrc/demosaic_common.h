@@ -103,3 +103,44 @@ DEVI void highpass_quad(const float W[4][4], float hf[4]) {
         }
 }
 
+// ---- finished RGB pixels of a quad -> global memory ---------------------------------------------------------------
+// Direct form: the quad's two rows as three 8-byte stores each (6 contiguous floats, 8-byte aligned because W is even).
+DEVI void store_quad_direct(float* out, int W, int qi, int qj, const float px[4][3]) {
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+        float2* o = reinterpret_cast<float2*>(out + ((size_t)(2 * qi + dy) * W + 2 * qj) * 3);
+        o[0] = make_float2(px[2 * dy][0], px[2 * dy][1]);
+        o[1] = make_float2(px[2 * dy][2], px[2 * dy + 1][0]);
+        o[2] = make_float2(px[2 * dy + 1][1], px[2 * dy + 1][2]);
+    }
+}
+// Staged form, for tiles that lie wholly inside the image when W % 4 == 0 (every image row then starts 16-byte aligned and
+// a tile row, TPX * 12 bytes, is a whole number of 16-byte pieces): every thread drops its quad into an LDS image of the
+// tile (8-byte LDS stores, lanes 24 bytes apart: conflict-free), then the workgroup streams the image out row by row with
+// one 16-byte store per lane, consecutive lanes on consecutive addresses -- whole 128-byte lines per wave instruction
+// instead of twelve dword stores per thread at a 12-byte stride.  `stage` may alias LDS that other threads still read:
+// the leading barrier separates that use.  Must be called by every thread of the workgroup.
+template <int TPX, int TPY, int NTHREADS>
+DEVI void stage_tile_store(float* stage, float* out, int W, int y0, int x0, int lqy, int lqx, const float px[4][3]) {
+    static_assert((TPX * 3) % 4 == 0, "a tile row is a whole number of 16-byte pieces");
+    constexpr int ROW = TPX * 3, ROW4 = ROW / 4, N4 = ROW4 * TPY;
+    __syncthreads();
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+        float2* o = reinterpret_cast<float2*>(stage + (2 * lqy + dy) * ROW + 6 * lqx);
+        o[0] = make_float2(px[2 * dy][0], px[2 * dy][1]);
+        o[1] = make_float2(px[2 * dy][2], px[2 * dy + 1][0]);
+        o[2] = make_float2(px[2 * dy + 1][1], px[2 * dy + 1][2]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (N4 + NTHREADS - 1) / NTHREADS; k++) {
+        const int idx = threadIdx.x + k * NTHREADS;
+        if (idx < N4) {
+            const int row = idx / ROW4, c4 = idx - row * ROW4;
+            const float4 v = *reinterpret_cast<const float4*>(stage + row * ROW + 4 * c4);
+            *reinterpret_cast<float4*>(out + ((size_t)(y0 + row) * W + x0) * 3 + 4 * c4) = v;
+        }
+    }
+}
+

@@ -33,6 +33,53 @@ DEVI float delta_mix(float top, float bottom, float left, float right) {
 }
 }  // namespace
 
+// P0 of both tile kernels: raw mosaic -> four de-interleaved quarter planes in LDS, halo 2 quads.  Slots outside the image
+// hold the BORDER_REFLECT (edge-duplicating) sample of their plane (eag.py:86-87).  mosaic_prefetch issues every global
+// load of a thread into registers (one 16-byte slot = two horizontally adjacent quads of one mosaic row), so they are in
+// flight together; mosaic_commit drops them into LDS.  Interior tiles with 16-byte aligned rows load a slot as ONE 16-byte access (a tile's first column,
+// 2 * (tq0x - 2), is a multiple of 4 floats); border tiles and uint16 mosaics take two pair loads with the border rule.
+constexpr int NSLOT4 = 2 * MWY * (MWX / 2), NL4 = (NSLOT4 + NT - 1) / NT;
+static_assert(MWX % 2 == 0 && TQX % 2 == 0, "a mosaic tile row is a whole number of 16-byte slots");
+template <bool TINY, bool U16>
+DEVI void mosaic_prefetch(const MosaicSrc& src, float4 tmp[NL4], int tid, int W, int h, int w, int tq0y, int tq0x, bool inside) {
+    if (!U16 && inside && !(W & 3)) {
+#pragma unroll
+        for (int k = 0; k < NL4; k++) {
+            int idx = tid + k * NT;
+            if (idx >= NSLOT4) idx = NSLOT4 - 1;
+            int ry = idx / (MWX / 2), m2 = idx - ry * (MWX / 2);
+            tmp[k] = *reinterpret_cast<const float4*>(src.f32 + (size_t)(2 * (tq0y - 2) + ry) * W + 2 * (tq0x - 2) + 4 * m2);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NL4; k++) {
+            int idx = tid + k * NT;
+            if (idx >= NSLOT4) idx = NSLOT4 - 1;
+            int ry = idx / (MWX / 2), m2 = idx - ry * (MWX / 2), my = ry >> 1, dy = ry & 1;
+            int qi = tq0y - 2 + my, qj0 = tq0x - 2 + 2 * m2, qj1 = qj0 + 1;
+            if (!inside) {                                                     // uniform per tile: interior tiles skip the border rules
+                qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
+                qj0 = TINY ? b_sym(qj0, w) : b_sym1(qj0, w);
+                qj1 = TINY ? b_sym(qj1, w) : b_sym1(qj1, w);
+            }
+            float2 lo = load_mosaic_pair<U16>(src, (size_t)(2 * qi + dy) * W + 2 * qj0, dy ? 3 : 0, dy ? 2 : 1);
+            float2 hi = load_mosaic_pair<U16>(src, (size_t)(2 * qi + dy) * W + 2 * qj1, dy ? 3 : 0, dy ? 2 : 1);
+            tmp[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+    }
+}
+DEVI void mosaic_commit(float (*mw)[MWY][MWX], const float4 tmp[NL4], int tid) {
+#pragma unroll
+    for (int k = 0; k < NL4; k++) {
+        int idx = tid + k * NT;
+        if (idx < NSLOT4) {
+            int ry = idx / (MWX / 2), m2 = idx - ry * (MWX / 2), my = ry >> 1, dy = ry & 1;
+            // even row: (R, G1, R, G1) ; odd row: (G2, B, G2, B)
+            *reinterpret_cast<float2*>(&mw[dy ? P_G2 : P_R][my][2 * m2]) = make_float2(tmp[k].x, tmp[k].z);
+            *reinterpret_cast<float2*>(&mw[dy ? P_B : P_G1][my][2 * m2]) = make_float2(tmp[k].y, tmp[k].w);
+        }
+    }
+}
 struct EagParams {
     MosaicSrc src;
     float* out;
@@ -45,41 +92,26 @@ struct EagParams {
 // TAIL is a template parameter: with the colour tail chosen at run time the kernel needs 66 VGPRs, with it fixed 40 (8 waves/SIMD)
 template <bool TINY, bool U16, int TAIL>
 __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
-    __shared__ float mw[4][MWY][MWX];
-    __shared__ float gq[4][GY][GX];
+    // one LDS block: the raw planes and the green / difference planes first, then (after a barrier) the finished RGB tile,
+    // which leaves the workgroup as whole 16-byte stores (stage_tile_store)
+    constexpr int NPLANES = 4 * MWY * MWX + 4 * GY * GX, NSTAGE = (2 * TQY) * (2 * TQX * 3);
+    __shared__ __attribute__((aligned(16))) float lds[NPLANES > NSTAGE ? NPLANES : NSTAGE];
+    float (*mw)[MWY][MWX] = reinterpret_cast<float (*)[MWY][MWX]>(lds);
+    float (*gq)[GY][GX] = reinterpret_cast<float (*)[GY][GX]>(lds + 4 * MWY * MWX);
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const bool inside = tq0y >= 2 && tq0x >= 2 && tq0y + TQY + 2 <= h && tq0x + TQX + 2 <= w;   // no border rule applies in P0/P1
-
-    // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87).  One 8-byte load per quad
-    // row; all loads of a thread are issued before the first LDS store so that they are in flight together.
+    // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87).
+    // (Measured and dropped: a workgroup looping over 2-16 consecutive tiles with the next tile's loads prefetched into registers
+    // during the compute phases: no gain at any tile count -- the kernel does not wait for bytes in flight -- and the loop form
+    // costs registers, 43 -> 79 VGPRs, 4 -> 3 workgroups per CU, +35 % time.)
     {
-        constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT - 1) / NT;
-        float2 tmp[NL];
-#pragma unroll
-        for (int k = 0; k < NL; k++) {
-            int idx = tid + k * NT;
-            if (idx >= NPAIR) idx = NPAIR - 1;
-            int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
-            int qi = tq0y - 2 + my, qj = tq0x - 2 + mx;
-            if (!inside) {                                                     // uniform per workgroup: interior tiles skip the border rules
-                qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
-                qj = TINY ? b_sym(qj, w) : b_sym1(qj, w);
-            }
-            tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
-        }
-#pragma unroll
-        for (int k = 0; k < NL; k++) {
-            int idx = tid + k * NT;
-            if (idx < NPAIR) {
-                int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
-                mw[dy ? P_G2 : P_R][my][mx] = tmp[k].x;
-                mw[dy ? P_B : P_G1][my][mx] = tmp[k].y;
-            }
-        }
+        float4 pre[NL4];
+        mosaic_prefetch<TINY, U16>(p.src, pre, tid, W, h, w, tq0y, tq0x, inside);
+        mosaic_commit(mw, pre, tid);
     }
     __syncthreads();
 
@@ -104,7 +136,11 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     // P2
     const int lqy = tid / TQX, lqx = tid - lqy * TQX;
     const int qi = tq0y + lqy, qj = tq0x + lqx;
-    if (qi >= h || qj >= w) return;
+    const bool live = qi < h && qj < w;
+    // whole tile inside the image and rows 16-byte aligned: the tile goes out through LDS as 16-byte stores
+    const bool staged = !(W & 3) && tq0y + TQY <= h && tq0x + TQX <= w;
+    float px[4][3];
+    if (live) {
     const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
     const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
     const float wg = p.wb[1];
@@ -141,9 +177,11 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     for (int k = 0; k < 4; k++) {
         float r = rr[k], g = gg[k], b = bb[k];
         colour_tail(TAIL, p.ccm.m, r, g, b);
-        float* o = p.out + ((size_t)(2 * qi + (k >> 1)) * W + (2 * qj + (k & 1))) * 3;
-        o[0] = r; o[1] = g; o[2] = b;
+        px[k][0] = r; px[k][1] = g; px[k][2] = b;
     }
+    if (!staged) store_quad_direct(p.out, W, qi, qj, px);
+    }
+    if (staged) stage_tile_store<2 * TQX, 2 * TQY, NT>(lds, p.out, W, 2 * tq0y, 2 * tq0x, lqy, lqx, px);
 }
 
 int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
@@ -176,18 +214,14 @@ int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
 // ================================================================================================
 // Draft (fast_resize.py:21-39): quarter-resolution RGB with 3/4-1/4 diagonal R/B alignment, then
 // bilinear x2 (half-pixel centres, edge clamp; horizontal pass then vertical pass).
+//
+// One workgroup = one 64x32 px output tile = 32x16 quads, one thread per quad (the EAG tile):
+//   P0  raw mosaic -> four de-interleaved quarter planes in LDS (halo 2 quads), 16-byte loads on interior tiles
+//   P1  quarter-resolution RGB q (halo 1 quad), positions outside the image take the clamped position (cv2.resize
+//       clamps its taps to the image)
+//   P2  per quad: the four bilinear outputs from q, colour tail, tile out through LDS as 16-byte stores
 namespace {
-template <bool U16>
-DEVI void draft_q(const MosaicSrc& bay, int h, int w, int W, int i, int j, const float wb[3], float q[3]) {
-    int i1 = i + 1 < h ? i + 1 : h - 1, j1 = j + 1 < w ? j + 1 : w - 1;   // r padded bottom/right (REFLECT)
-    int i0 = i > 0 ? i - 1 : 0, j0 = j > 0 ? j - 1 : 0;                   // b padded top/left
-    float r = load_mosaic<U16>(bay, (size_t)(2 * i) * W + 2 * j, 0), rd = load_mosaic<U16>(bay, (size_t)(2 * i1) * W + 2 * j1, 0);
-    float b = load_mosaic<U16>(bay, (size_t)(2 * i + 1) * W + 2 * j + 1, 2), bd = load_mosaic<U16>(bay, (size_t)(2 * i0 + 1) * W + 2 * j0 + 1, 2);
-    float g1 = load_mosaic<U16>(bay, (size_t)(2 * i) * W + 2 * j + 1, 1), g2 = load_mosaic<U16>(bay, (size_t)(2 * i + 1) * W + 2 * j, 3);
-    q[0] = (0.75f * r + 0.25f * rd) * wb[0];
-    q[1] = ((g1 + g2) / 2.0f) * wb[1];
-    q[2] = (0.75f * b + 0.25f * bd) * wb[2];
-}
+// cv2.resize INTER_LINEAR x2 along one axis for output position X of n input samples: taps s0, s1 and weights 1-f, f
 DEVI void lin_tap(int X, int n, int& s0, int& s1, float& a0, float& a1) {
     float f = ((float)X + 0.5f) * 0.5f - 0.5f;
     int s = (int)floorf(f);
@@ -196,28 +230,81 @@ DEVI void lin_tap(int X, int n, int& s0, int& s1, float& a0, float& a1) {
     if (s >= n - 1) { s = n - 1; f = 0.0f; }
     s0 = s; s1 = s + 1 < n ? s + 1 : s; a0 = 1.0f - f; a1 = f;
 }
+constexpr int DQX = TQX + 2, DQY = TQY + 2;     // q planes, halo 1 quad
 }  // namespace
 
-template <bool U16>
-__global__ void __launch_bounds__(256) k_draft(EagParams p) {
-    int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+template <bool TINY, bool U16, int TAIL>
+__global__ void __launch_bounds__(NT) k_draft(EagParams p) {
+    constexpr int NPLANES = 4 * MWY * MWX + 3 * DQY * DQX, NSTAGE = (2 * TQY) * (2 * TQX * 3);
+    __shared__ __attribute__((aligned(16))) float lds[NPLANES > NSTAGE ? NPLANES : NSTAGE];
+    float (*mw)[MWY][MWX] = reinterpret_cast<float (*)[MWY][MWX]>(lds);
+    float (*q)[DQY][DQX] = reinterpret_cast<float (*)[DQY][DQX]>(lds + 4 * MWY * MWX);
+    const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
-    if (X >= W) return;
-    int sx0, sx1, sy0, sy1; float a0, a1, b0, b1;
-    lin_tap(X, w, sx0, sx1, a0, a1);
-    lin_tap(Y, h, sy0, sy1, b0, b1);
-    float q00[3], q01[3], q10[3], q11[3];
-    draft_q<U16>(p.src, h, w, W, sy0, sx0, p.wb, q00); draft_q<U16>(p.src, h, w, W, sy0, sx1, p.wb, q01);
-    draft_q<U16>(p.src, h, w, W, sy1, sx0, p.wb, q10); draft_q<U16>(p.src, h, w, W, sy1, sx1, p.wb, q11);
-    float o[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float h0 = q00[c] * a0 + q01[c] * a1, h1 = q10[c] * a0 + q11[c] * a1;
-        o[c] = h0 * b0 + h1 * b1;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int tq0x = tbx * TQX, tq0y = tby * TQY;
+    const bool inside = tq0y >= 2 && tq0x >= 2 && tq0y + TQY + 2 <= h && tq0x + TQX + 2 <= w;   // no clamp applies anywhere in the tile
+    {
+        float4 pre[NL4];
+        mosaic_prefetch<TINY, U16>(p.src, pre, tid, W, h, w, tq0y, tq0x, inside);
+        mosaic_commit(mw, pre, tid);
     }
-    colour_tail(p.tail, p.ccm.m, o[0], o[1], o[2]);
-    float* d = p.out + ((size_t)Y * W + X) * 3;
-    d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+    __syncthreads();
+
+    // P1: q = (R, G, B) at quarter resolution (fast_resize.py:28-37): r padded bottom/right, b padded top/left (REFLECT by one = the edge sample)
+    for (int idx = tid; idx < DQY * DQX; idx += NT) {
+        int gy = idx / DQX, gx = idx - gy * DQX;
+        int a = gy + 1, c = gx + 1, a1 = a + 1, c1 = c + 1, a0 = a - 1, c0 = c - 1;            // slots in the staged planes (origin tq0 - 2)
+        if (!inside) {
+            int qi = b_rep(tq0y - 1 + gy, h), qj = b_rep(tq0x - 1 + gx, w);
+            a = qi - (tq0y - 2); c = qj - (tq0x - 2);
+            a1 = b_rep(qi + 1, h) - (tq0y - 2); c1 = b_rep(qj + 1, w) - (tq0x - 2);
+            a0 = b_rep(qi - 1, h) - (tq0y - 2); c0 = b_rep(qj - 1, w) - (tq0x - 2);
+            if (a0 < 0 || a1 > MWY - 1 || c0 < 0 || c1 > MWX - 1) continue;                      // beyond a partial tile: never consumed
+        }
+        q[0][gy][gx] = (0.75f * mw[P_R][a][c] + 0.25f * mw[P_R][a1][c1]) * p.wb[0];
+        q[1][gy][gx] = ((mw[P_G1][a][c] + mw[P_G2][a][c]) / 2.0f) * p.wb[1];
+        q[2][gy][gx] = (0.75f * mw[P_B][a][c] + 0.25f * mw[P_B][a0][c0]) * p.wb[2];
+    }
+    __syncthreads();
+
+    // P2
+    const int lqy = tid / TQX, lqx = tid - lqy * TQX;
+    const int qi = tq0y + lqy, qj = tq0x + lqx;
+    const bool live = qi < h && qj < w;
+    const bool staged = !(W & 3) && tq0y + TQY <= h && tq0x + TQX <= w;
+    float px[4][3];
+    if (live) {
+        // taps of the two output columns / rows of this quad, as slots of the q planes (origin tq0 - 1)
+        int sx[2][2], sy[2][2];
+        float ax[2][2], ay[2][2];
+        if (inside) {      // interior: X = 2j -> (j-1, j) weights (1/4, 3/4); X = 2j+1 -> (j, j+1) weights (3/4, 1/4); lin_tap gives exactly these
+            sx[0][0] = lqx; sx[0][1] = lqx + 1; sx[1][0] = lqx + 1; sx[1][1] = lqx + 2;
+            sy[0][0] = lqy; sy[0][1] = lqy + 1; sy[1][0] = lqy + 1; sy[1][1] = lqy + 2;
+            ax[0][0] = ay[0][0] = 0.25f; ax[0][1] = ay[0][1] = 0.75f; ax[1][0] = ay[1][0] = 0.75f; ax[1][1] = ay[1][1] = 0.25f;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                lin_tap(2 * qj + d, w, sx[d][0], sx[d][1], ax[d][0], ax[d][1]);
+                lin_tap(2 * qi + d, h, sy[d][0], sy[d][1], ay[d][0], ay[d][1]);
+                sx[d][0] -= tq0x - 1; sx[d][1] -= tq0x - 1; sy[d][0] -= tq0y - 1; sy[d][1] -= tq0y - 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int dy = k >> 1, dx = k & 1;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float h0 = q[c][sy[dy][0]][sx[dx][0]] * ax[dx][0] + q[c][sy[dy][0]][sx[dx][1]] * ax[dx][1];
+                float h1 = q[c][sy[dy][1]][sx[dx][0]] * ax[dx][0] + q[c][sy[dy][1]][sx[dx][1]] * ax[dx][1];
+                px[k][c] = h0 * ay[dy][0] + h1 * ay[dy][1];
+            }
+            colour_tail(TAIL, p.ccm.m, px[k][0], px[k][1], px[k][2]);
+        }
+        if (!staged) store_quad_direct(p.out, W, qi, qj, px);
+    }
+    if (staged) stage_tile_store<2 * TQX, 2 * TQY, NT>(lds, p.out, W, 2 * tq0y, 2 * tq0x, lqy, lqx, px);
 }
 
 int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
@@ -225,10 +312,24 @@ int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float
     a.src = src; a.out = d_out; a.H = H; a.W = W; a.tail = tail;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
-    dim3 g((W + 255) / 256, H);
+    dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_draft");
-    if (src.u16) hipLaunchKernelGGL(k_draft<true>, g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_draft<false>, g, dim3(256), 0, st, a);
+    const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
+#define DRAFT_LAUNCH(T) \
+    do { \
+        if (tiny && u16) hipLaunchKernelGGL((k_draft<true, true, T>), g, dim3(NT), 0, st, a); \
+        else if (tiny) hipLaunchKernelGGL((k_draft<true, false, T>), g, dim3(NT), 0, st, a); \
+        else if (u16) hipLaunchKernelGGL((k_draft<false, true, T>), g, dim3(NT), 0, st, a); \
+        else hipLaunchKernelGGL((k_draft<false, false, T>), g, dim3(NT), 0, st, a); \
+    } while (0)
+    switch (tail) {
+        case 0: DRAFT_LAUNCH(0); break;
+        case 1: DRAFT_LAUNCH(1); break;
+        case 2: DRAFT_LAUNCH(2); break;
+        case 3: DRAFT_LAUNCH(3); break;
+        default: return -1;
+    }
+#undef DRAFT_LAUNCH
     if (tl) tl->end(st);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
