@@ -266,3 +266,37 @@ def test_bench_default_line_contract():
     assert r["valu"] and 0 < r["valu"]["frac_of_2cycle_issue"] <= 1.0 and r["valu"]["insts_per_px"] > 100
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+
+
+# ---- the sRGB curve, every float32 in [0, 1] --------------------------------------------------------
+def test_srgb_curve_exhaustive(orc):
+    """lin_srgb_to_srgb (transform.py:89-99) on ALL 1,065,353,217 float32 values of [0, 1] (every bit pattern from 0 to
+    0x3F800000) plus a band above 1 and the negative side: the kernel's x ** 0.41666666f (devmath.h::srgb_pow_5_12, hardware
+    log2/exp2 seed + one float64 Newton-type correction) against the oracle's float64 pow rounded once.  Claim: bit-identical
+    on every input (north_star asks for 1 ULP)."""
+    import ctypes
+    import torch
+    from pysp_amd import _lib
+    L, ctx = _lib.lib(), _lib.Context(0)
+    ctx.set_stream(int(torch.cuda.current_stream().cuda_stream))     # same stream as torch's arange below: ordered, no host sync needed
+    chunk = 1 << 26
+    hi = 0x3F800000 + 4096                      # a little beyond 1.0: clipped
+    worst, differ, n = 0, 0, 0
+    out = torch.empty(chunk, dtype=torch.float32, device="cuda")
+    for lo in range(0, hi, chunk):
+        m = min(chunk, hi - lo)
+        x = torch.arange(lo, lo + m, dtype=torch.int32, device="cuda").view(torch.float32)
+        _lib.check(L.pysp_lin_srgb_to_srgb_dev(ctx.handle, ctypes.c_void_p(x.data_ptr()), m, ctypes.c_void_p(out.data_ptr())))
+        ctx.sync()
+        got = out[:m].cpu().numpy()
+        ref = orc.lin_srgb_to_srgb(x.cpu().numpy())
+        bad = got != ref
+        if bad.any():
+            differ += int(bad.sum())
+            worst = max(worst, int(ulp_diff(got[bad], ref[bad]).max()))
+        n += m
+    neg = np.array([-0.0, -1e-30, -1.0, -np.inf], np.float32)
+    from pysp_amd.colorize.transform import lin_srgb_to_srgb
+    assert np.array_equal(lin_srgb_to_srgb(neg.reshape(1, -1, 1).repeat(3, axis=2)), np.zeros((1, 4, 3), np.float32))
+    print(f"sRGB curve: {n} inputs, {differ} differ from the oracle, worst {worst} ULP")
+    assert n > 1_065_353_216 and differ == 0, (n, differ, worst)
