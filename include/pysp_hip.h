@@ -12,7 +12,8 @@
  *   - entry points return 0 on success and a negative PYSP_E* code on failure;
  *     pysp_last_error() returns a thread-local description of the last failure;
  *   - "host" entry points borrow caller memory for the duration of the call (outputs are written
- *     into caller-allocated buffers, like the np.zeros outputs of the Cython units);
+ *     into caller-allocated buffers, like the np.zeros outputs of the Cython units); large frames go
+ *     through the GPU in horizontal bands so that upload, kernels and download overlap;
  *   - "_dev" entry points take device pointers and only enqueue work on the context's stream;
  *   - a pysp_ctx owns one HIP stream and a grow-only device workspace; it is not thread-safe,
  *     use one context per thread.  There is no CPU fallback: without a GPU, pysp_ctx_create fails.
@@ -73,6 +74,15 @@ int pysp_ctx_last_kernel_ms(pysp_ctx *ctx, float *ms);
  * and static names of the kernels of the most recent such call (waits for them). */
 int pysp_ctx_set_kernel_timing(pysp_ctx *ctx, int mode);
 int pysp_ctx_kernel_times(pysp_ctx *ctx, int max_kernels, float *ms, const char **names, int *n_out);
+
+/* Device buffers for callers that keep images on the GPU between calls and have no allocator of their own (the lazily
+ * materialised arrays of the Python drop-in classes: RawDemosaicData.image, base_types/image_base.py:19-35, stays in HBM until
+ * somebody reads it).  Freed blocks are cached by the context; reuse is safe because every consumer enqueues on the context's
+ * stream.  upload enqueues (the host buffer must stay valid until the next synchronising call); download waits. */
+void *pysp_dev_alloc(pysp_ctx *ctx, size_t bytes);
+int pysp_dev_free(pysp_ctx *ctx, void *dptr);
+int pysp_dev_upload(pysp_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int pysp_dev_download(pysp_ctx *ctx, void *host, const void *dptr, size_t bytes);
 
 /* ---- Bayer plane helpers -------------------------------------------------------------------- */
 /* bayer_chan_mixer.py:4-21 bayer_to_rgbg (float32 or uint16 mosaic -> four float32 quarter planes) */
@@ -135,6 +145,7 @@ int pysp_lin_srgb_to_srgb_dev(pysp_ctx *ctx, const float *d_in, size_t n, float 
 int pysp_srgb_to_lin_srgb_f32(pysp_ctx *ctx, const float *in, size_t n, float *out);
 /* base_types/image_base.py:45-60 wb_apply (image*coeff -> f32) / wb_undo (f64 divide -> f32) */
 int pysp_wb_scale_f32(pysp_ctx *ctx, const float *in, size_t npx, const float coeff[3], int undo, float *out);
+int pysp_wb_scale_dev(pysp_ctx *ctx, const float *d_in, size_t npx, const float coeff[3], int undo, float *d_out);
 
 /* ---- Fused recipe (README.md:55-63): demosaic -> to_lin_srgb (clip on) -> [x/(1+x), README.md:157]
  * -> lin_srgb_to_srgb, one frame, no intermediate leaves the GPU.  srgb: (H,W,3) float32. */

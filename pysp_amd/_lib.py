@@ -42,6 +42,11 @@ _SIGNATURES = {
     "pysp_ctx_last_kernel_ms": (_int, [_vp, _f32p]),
     "pysp_ctx_set_kernel_timing": (_int, [_vp, _int]),
     "pysp_ctx_kernel_times": (_int, [_vp, _int, _f32p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_int)]),
+    "pysp_dev_alloc": (_vp, [_vp, _sz]),
+    "pysp_dev_free": (_int, [_vp, _vp]),
+    "pysp_dev_upload": (_int, [_vp, _vp, _vp, _sz]),
+    "pysp_dev_download": (_int, [_vp, _vp, _vp, _sz]),
+    "pysp_wb_scale_dev": (_int, [_vp, _vp, _sz, _f32p, _int, _vp]),
     "pysp_bayer_to_rgbg_f32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pysp_bayer_to_rgbg_u16": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pysp_rgbg_to_bayer_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _vp]),

@@ -10,6 +10,7 @@ import numpy as np
 from .. import _lib
 from ..colorize.transform import cam_to_lin_srgb
 from ..const import QualityDemosaic
+from ..device_array import DeviceArray
 from ..wb_cct.helpers_cam_mat import MatXyzToCamera
 
 BayerPattern = enum.IntEnum("BayerPattern", ("Rggb", "Bggr", "Grbg", "Gbrg"), module=__name__)
@@ -19,19 +20,42 @@ class RawDemosaicData:
     """(H, W, 3) float32 camera-space RGB produced by a demosaic, plus what is needed to colour it."""
 
     def __init__(self, image: np.ndarray, wb_coeff: np.ndarray, wb_norm: bool = False):
-        self.image = image                 # white-balanced camera RGB
+        self.image = image                 # white-balanced camera RGB (a property: see below)
         self.mat_xyz: Optional[MatXyzToCamera] = None
         self.current_ev: float = np.inf
         self._wb_coeff = wb_coeff          # reciprocal neutral multipliers, at least 3 entries
         self._wb_applied = True            # every demosaic path multiplies them in (ahd.py:77-80, eag.py:193-194)
         self._wb_normalized = wb_norm
 
+    # `image` is the plain ndarray attribute of the reference (image_base.py:27) to every reader and writer.  Behind it a
+    # demosaic result lives in HBM (DeviceArray) until the attribute is first READ: then it is downloaded once, the device copy
+    # is dropped (the caller may change the ndarray in place, which the GPU copy would not see) and the ndarray is the image
+    # from then on.  to_lin_srgb() / wb_apply() / wb_undo() use the device copy while it exists and never trigger the download.
+    @property
+    def image(self):
+        if self._dev is not None:
+            self._img = self._dev.numpy()
+            self._dev.release()
+            self._dev = None
+        return self._img
+
+    @image.setter
+    def image(self, value):
+        if isinstance(value, DeviceArray) and value.on_device:
+            self._dev, self._img = value, None
+        else:
+            self._dev, self._img = None, (value.numpy() if isinstance(value, DeviceArray) else value)
+
     def is_valid(self) -> bool:
         """Image, coefficients, matrix and exposure value are all present."""
-        have = (self.image is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
+        have = (self._dev is not None or self._img is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
         return all(have)
 
-    def _gpu_scale(self, undo: bool) -> np.ndarray:
+    def _gpu_scale(self, undo: bool):
+        if self._dev is not None:                      # still in HBM: scale there, stay there
+            dst = DeviceArray(self._dev.context, self._dev.shape)
+            _lib.check(_lib.lib().pysp_wb_scale_dev(self._dev.context.handle, self._dev.ptr, self._dev.size // 3, _lib.wb3(self._wb_coeff), int(undo), dst.ptr))
+            return dst
         src = _lib.f32c(self.image)
         dst = np.empty_like(src)
         _lib.check(_lib.lib().pysp_wb_scale_f32(_lib.default_context().handle, _lib.ptr(src), src.size // 3,
@@ -57,7 +81,7 @@ class RawDemosaicData:
     def to_lin_srgb(self) -> np.ndarray:
         """Linear sRGB through the camera matrix, highlights clipped (image_base.py:62-64)."""
         self.wb_apply()
-        return cam_to_lin_srgb(self.image, self.mat_xyz)
+        return cam_to_lin_srgb(self._dev if self._dev is not None else self.image, self.mat_xyz)
 
 
 class RawCameraData_BaseType:

@@ -10,6 +10,7 @@ import ctypes
 import numpy as np
 
 from .. import _lib
+from ..device_array import DeviceArray, lazy_enabled
 from ..wb_cct.helpers_cam_mat import MatXyzToCamera
 from .rgb_space import ArbitraryRgbColorspace, LinRgbColorspace
 
@@ -20,6 +21,10 @@ def final_matrix(cam_xyz_matrix: MatXyzToCamera, destination_colorspace: Arbitra
     m = np.matmul(cam_xyz_matrix.mat, to_xyz)
     m = m / m.sum(axis=1)[:, np.newaxis]        # neutral in -> neutral out
     return np.linalg.inv(m)
+
+
+def _on_device(x) -> bool:
+    return isinstance(x, DeviceArray) and x.on_device and lazy_enabled()
 
 
 def _rgb_image(rgb: np.ndarray) -> np.ndarray:
@@ -36,8 +41,14 @@ def clip_rgb(rgb: np.ndarray) -> np.ndarray:
 
 def cam_to_rgb_norm(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, destination_colorspace: ArbitraryRgbColorspace,
                     clip_highlights: bool = True) -> np.ndarray:
-    a = _rgb_image(rgb)
     M = final_matrix(cam_xyz_matrix, destination_colorspace)
+    if _on_device(rgb):                              # intermediate of the README recipe: stays in HBM (lazy DeviceArray)
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise ValueError("expected an (H, W, 3) RGB image")
+        out = DeviceArray(rgb.context, rgb.shape)
+        _lib.check(_lib.lib().pysp_cam_to_rgb_dev(rgb.context.handle, rgb.ptr, rgb.size // 3, _lib.mat9(M), int(bool(clip_highlights)), out.ptr))
+        return out
+    a = _rgb_image(rgb)
     out = np.empty_like(a)
     _lib.check(_lib.lib().pysp_cam_to_rgb_f32(_lib.default_context().handle, _lib.ptr(a), a.size // 3, _lib.mat9(M),
                                               int(bool(clip_highlights)), _lib.ptr(out)))
@@ -66,7 +77,16 @@ def _flat(fn_name: str, x: np.ndarray) -> np.ndarray:
 
 
 def lin_srgb_to_srgb(rgb: np.ndarray) -> np.ndarray:
-    """Clip to [0,1] and apply the sRGB transfer curve (transform.py:89-99)."""
+    """Clip to [0,1] and apply the sRGB transfer curve (transform.py:89-99).  Always returns a real ndarray: given the lazy
+    result of to_lin_srgb() it encodes on the GPU and downloads once (the end of the README recipe)."""
+    if _on_device(rgb):
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise ValueError("expected an (H, W, 3) RGB image")
+        tmp = DeviceArray(rgb.context, rgb.shape)
+        _lib.check(_lib.lib().pysp_lin_srgb_to_srgb_dev(rgb.context.handle, rgb.ptr, ctypes.c_size_t(rgb.size), tmp.ptr))
+        out = tmp.numpy()
+        tmp.release()
+        return out
     return _flat("pysp_lin_srgb_to_srgb_f32", _rgb_image(rgb))
 
 

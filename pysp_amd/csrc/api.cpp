@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/pysp_hip.h"
@@ -59,6 +61,12 @@ struct pysp_ctx {
     float* lanczos = nullptr;
     float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
     Timeline tl;
+    // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    // device buffers handed to callers that keep images on the GPU between calls (pysp_dev_alloc): freed blocks are cached
+    struct Block { void* p; size_t cap; bool used; };
+    std::vector<Block> blocks;
 
     int reserve(int i, size_t bytes, void** out) {
         if (bytes > cap[i]) {
@@ -178,6 +186,9 @@ void pysp_ctx_destroy(pysp_ctx* c) {
     hipError_t e = guard.enter(c->device); (void)e;
     e = hipStreamSynchronize(c->stream); (void)e;
     for (int i = 0; i < pysp_ctx::NSLOT; i++) if (c->slot[i]) { e = hipFree(c->slot[i]); (void)e; }
+    for (auto& b : c->blocks) if (b.p) { e = hipFree(b.p); (void)e; }
+    if (c->copy_stream) { e = hipStreamDestroy(c->copy_stream); (void)e; }
+    for (int i = 0; i < 2; i++) if (c->ev_done[i]) { e = hipEventDestroy(c->ev_done[i]); (void)e; }
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
     if (c->labtab) { e = hipFree(c->labtab); (void)e; }
     for (int i = 0; i < 2 * Timeline::MAXK; i++) if (c->tl.ev[i]) { e = hipEventDestroy(c->tl.ev[i]); (void)e; }
@@ -237,13 +248,69 @@ int pysp_ctx_kernel_times(pysp_ctx* ctx, int max_kernels, float* ms, const char*
     return PYSP_OK;
 }
 
+// ---- device buffers for callers without an allocator of their own (the lazy arrays of the Python drop-in classes) ------------
+void* pysp_dev_alloc(pysp_ctx* ctx, size_t bytes) {
+    if (!ctx || bytes == 0) { fail(PYSP_EBADARG, "dev_alloc: null context or zero size"); return nullptr; }
+    DevGuard guard;
+    if (guard.enter(ctx->device) != hipSuccess) { fail(PYSP_EHIP, "hipSetDevice failed"); return nullptr; }
+    pysp_ctx::Block* best = nullptr;
+    for (auto& b : ctx->blocks)                                   // smallest cached block that fits without wasting more than half
+        if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
+    if (best) { best->used = true; return best->p; }
+    void* p = nullptr;
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {                                        // release the cache and try once more
+        for (auto& b : ctx->blocks) if (!b.used && b.p) { hipError_t f = hipFree(b.p); (void)f; b.p = nullptr; b.cap = 0; }
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) { fail(PYSP_ENOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); return nullptr; }
+    for (auto& b : ctx->blocks) if (!b.p) { b = {p, want, true}; return p; }
+    ctx->blocks.push_back({p, want, true});
+    return p;
+}
+int pysp_dev_free(pysp_ctx* ctx, void* dptr) {
+    CTX_ENTER(ctx);
+    if (!dptr) return PYSP_OK;
+    size_t cached = 0;
+    for (auto& b : ctx->blocks) if (!b.used && b.p) cached += b.cap;
+    for (auto& b : ctx->blocks)
+        if (b.p == dptr && b.used) {
+            b.used = false;                                       // stream order protects reuse: every consumer enqueues on the context's stream
+            if (cached + b.cap > ((size_t)8 << 30)) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+            return PYSP_OK;
+        }
+    return fail(PYSP_EBADARG, "dev_free: not a buffer of this context");
+}
+int pysp_dev_upload(pysp_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+    CTX_ENTER(ctx);
+    if (!dptr || !host) return fail(PYSP_EBADARG, "dev_upload: null pointer");
+    HIP_TRY(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PYSP_OK;
+}
+int pysp_dev_download(pysp_ctx* ctx, void* host, const void* dptr, size_t bytes) {
+    CTX_ENTER(ctx);
+    if (!dptr || !host) return fail(PYSP_EBADARG, "dev_download: null pointer");
+    HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PYSP_OK;
+}
+int pysp_wb_scale_dev(pysp_ctx* ctx, const float* d_in, size_t npx, const float coeff[3], int undo, float* d_out) {
+    CTX_ENTER(ctx);
+    if (!d_in || !d_out || !coeff) return fail(PYSP_EBADARG, "wb_scale: null pointer");
+    ctx->tic();
+    LAUNCH_TRY(launch_wb_scale(ctx->stream, d_in, npx, coeff, undo, d_out));
+    ctx->toc();
+    return PYSP_OK;
+}
+
 // ---- helpers ------------------------------------------------------------------------------------
 static int h2d(pysp_ctx* c, void* d, const void* h, size_t n) { HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream)); return PYSP_OK; }
 static int d2h(pysp_ctx* c, void* h, const void* d, size_t n) { HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream)); return PYSP_OK; }
 #define TRY(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 // slots: 0 input A, 1 output A, 2/3 AHD scratch, 4..7 planes, 8 aux, 9.. HDR frames
-enum { S_IN = 0, S_OUT = 1, S_TMP0 = 2, S_TMP1 = 3, S_P0 = 4, S_AUX = 8, S_FR0 = 9 };
+enum { S_IN = 0, S_OUT = 1, S_TMP0 = 2, S_TMP1 = 3, S_P0 = 4, S_AUX = 8, S_FR0 = 9, S_IN2 = 30, S_OUT2 = 31 };
 
 // ---- Bayer helpers --------------------------------------------------------------------------------
 extern "C++" template <typename T>
@@ -413,17 +480,79 @@ static int run_pipeline_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, c
     if (!d_bayer) return fail(PYSP_EBADARG, "demosaic: null pointer");
     return run_pipeline_src(ctx, mosaic_f32(d_bayer), H, W, wb, M, quality, hdr, stages, tail, d_out);
 }
-static int run_pipeline_host(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
-                             int stages, int tail, float* out) {
+// Host-buffer form of every pipeline.  The frame is cut into horizontal bands that go through the GPU one after the other:
+// upload of band b+1 (with the stencil halo the kernels need, taken from the caller's own rows) and its kernels run on the
+// context's stream while a helper thread downloads band b on a second stream, so the two PCIe directions and the kernels
+// overlap (pageable copies block the thread that issues them, hence the thread).  Interior cuts are exact: every kernel's
+// stencil is covered by the halo (8 + 4 * stages rows, as in pysp_amd/multi_gpu.py::band_ranges); true image borders keep
+// the reference's border rules because a band that touches one is not extended there.
+extern "C++" template <typename T>
+static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black, const float* sat, int H, int W, const float wb[3],
+                               const double M[9], int quality, int hdr, int stages, int tail, float* out) {
     if (!bayer || !out) return fail(PYSP_EBADARG, "demosaic: null pointer");
     if (!even_dims(H, W)) return fail(PYSP_EBADARG, "demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
-    size_t N = (size_t)H * W;
-    float *d_in, *d_out;
-    RESERVE(ctx, S_IN, N * 4, d_in); RESERVE(ctx, S_OUT, N * 12, d_out);
-    TRY(h2d(ctx, d_in, bayer, N * 4));
-    TRY(run_pipeline_dev(ctx, d_in, H, W, wb, M, quality, hdr, stages, tail, d_out));
-    TRY(d2h(ctx, out, d_out, N * 12));
+    if (quality < PYSP_QUALITY_DRAFT || quality > PYSP_QUALITY_BEST) return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
+    const int st = stages < 0 ? 0 : stages;
+    const int halo = 8 + 4 * st;
+    int band = 512;                                              // output rows per band (even)
+    const size_t px = (size_t)H * W;
+    int nb = px < ((size_t)1 << 22) ? 1 : (H + band - 1) / band;  // small frames: one piece
+    if (nb < 2) { nb = 1; band = H; }
+    const int max_rows = (band + 2 * halo) < H ? (band + 2 * halo) : H;
+    T* d_in[2]; float* d_out[2];
+    for (int i = 0; i < (nb > 1 ? 2 : 1); i++) {
+        RESERVE(ctx, i == 0 ? S_IN : S_IN2, (size_t)max_rows * W * sizeof(T), d_in[i]);
+        RESERVE(ctx, i == 0 ? S_OUT : S_OUT2, (size_t)max_rows * W * 12, d_out[i]);
+    }
+    auto mosaic = [&](const T* d) { return sizeof(T) == 2 ? mosaic_u16(reinterpret_cast<const uint16_t*>(d), black, sat) : mosaic_f32(reinterpret_cast<const float*>(d)); };
+    if (nb == 1) {
+        TRY(h2d(ctx, d_in[0], bayer, px * sizeof(T)));
+        TRY(run_pipeline_src(ctx, mosaic(d_in[0]), H, W, wb, M, quality, hdr, stages, tail, d_out[0]));
+        TRY(d2h(ctx, out, d_out[0], px * 12));
+        return pysp_ctx_sync(ctx);
+    }
+    if (!ctx->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+    }
+    // produced[b]: band b's kernels are enqueued and ev_done[b & 1] recorded; consumed: bands whose download has finished
+    std::atomic<int> produced{0}, consumed{0}, worker_rc{PYSP_OK};
+    std::atomic<bool> abort{false};
+    const int device = ctx->device;
+    std::thread worker([&] {
+        if (hipSetDevice(device) != hipSuccess) { worker_rc = PYSP_EHIP; consumed = nb; return; }
+        for (int b = 0; b < nb; b++) {
+            while (produced.load(std::memory_order_acquire) <= b) { if (abort.load()) { consumed = nb; return; } std::this_thread::yield(); }
+            const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H, r0 = y0 - halo > 0 ? y0 - halo : 0;
+            hipError_t e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)y0 * W * 3, d_out[i] + (size_t)(y0 - r0) * W * 3, (size_t)(y1 - y0) * W * 12, hipMemcpyDeviceToHost, ctx->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+            if (e != hipSuccess) worker_rc = PYSP_EHIP;
+            consumed.store(b + 1, std::memory_order_release);
+        }
+    });
+    int rc = PYSP_OK;
+    for (int b = 0; b < nb && rc == PYSP_OK; b++) {
+        const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
+        const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
+        while (consumed.load(std::memory_order_acquire) < b - 1) std::this_thread::yield();      // buffer i is free again once band b-2 has left it
+        hipError_t e = hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { rc = fail(PYSP_EHIP, "hipMemcpyAsync H2D: %s", hipGetErrorString(e)); break; }
+        rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
+        if (rc != PYSP_OK) break;
+        e = hipEventRecord(ctx->ev_done[i], ctx->stream);
+        if (e != hipSuccess) { rc = fail(PYSP_EHIP, "hipEventRecord: %s", hipGetErrorString(e)); break; }
+        produced.store(b + 1, std::memory_order_release);
+    }
+    if (rc != PYSP_OK) abort = true;
+    worker.join();
+    if (rc != PYSP_OK) return rc;
+    if (worker_rc.load() != PYSP_OK) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(hipGetLastError()));
     return pysp_ctx_sync(ctx);
+}
+static int run_pipeline_host(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
+                             int stages, int tail, float* out) {
+    return run_pipeline_host_t<float>(ctx, bayer, nullptr, nullptr, H, W, wb, M, quality, hdr, stages, tail, out);
 }
 int pysp_demosaic_f32(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, float* rgb) {
     CTX_ENTER(ctx);
@@ -466,15 +595,9 @@ int pysp_pipeline_u16_dev(pysp_ctx* ctx, const uint16_t* d_bayer, int H, int W, 
 int pysp_pipeline_u16_f32(pysp_ctx* ctx, const uint16_t* bayer, int H, int W, const float black[4], const float sat[4], const float wb[3],
                           const double M[9], int quality, int hdr, int stages, int tail, float* out) {
     CTX_ENTER(ctx);
-    if (!bayer || !out) return fail(PYSP_EBADARG, "pipeline_u16: null pointer");
-    if (!even_dims(H, W)) return fail(PYSP_EBADARG, "pipeline_u16: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
-    size_t N = (size_t)H * W;
-    uint16_t* d_in; float* d_out;
-    RESERVE(ctx, S_IN, N * 2, d_in); RESERVE(ctx, S_OUT, N * 12, d_out);
-    TRY(h2d(ctx, d_in, bayer, N * 2));
-    TRY(pysp_pipeline_u16_dev(ctx, d_in, H, W, black, sat, wb, M, quality, hdr, stages, tail, d_out));
-    TRY(d2h(ctx, out, d_out, N * 12));
-    return pysp_ctx_sync(ctx);
+    if (!bayer || !out || !black || !sat) return fail(PYSP_EBADARG, "pipeline_u16: null pointer");
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_u16: tail must be 0..3");
+    return run_pipeline_host_t<uint16_t>(ctx, bayer, black, sat, H, W, wb, M, quality, hdr, stages, tail, out);
 }
 
 // ---- colour ---------------------------------------------------------------------------------------

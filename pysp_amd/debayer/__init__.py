@@ -6,6 +6,7 @@ import numpy as np
 from .. import _lib
 from ..base_types.image_base import RawDemosaicData, RawRggbBayerData_BaseType
 from ..colorize.transform import final_matrix
+from ..device_array import DeviceArray, lazy_enabled
 from .ahd_homogeneity import build_map  # noqa: F401
 
 
@@ -14,13 +15,24 @@ def _run(image: RawRggbBayerData_BaseType, quality: int, stages: int = 0) -> Raw
     if bayer.ndim != 2:
         raise ValueError("sensor_scaled must be a 2-D mosaic")
     H, W = bayer.shape
+    if H < 2 or W < 2 or H % 2 or W % 2:
+        raise ValueError("demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)" % (H, W))
     wb = image.cam_wb.get_reciprocal_multipliers()
     mat = image.cam_wb.get_matrix()
     # The matrix only matters for AHD's homogeneity metric (ahd.py:46-48).
     M = _lib.mat9(final_matrix(mat)) if quality == _lib.QUALITY_BEST else None
-    rgb = np.empty((H, W, 3), np.float32)
-    _lib.check(_lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(bayer), H, W, _lib.wb3(wb), M, quality,
-                                            int(bool(image.get_hdr())), int(stages), _lib.ptr(rgb)))
+    if lazy_enabled():
+        # the result stays in HBM (DeviceArray) until somebody reads RawDemosaicData.image; to_lin_srgb() consumes it there
+        ctx = _lib.default_context()
+        src = DeviceArray.from_host(ctx, bayer)
+        rgb = DeviceArray(ctx, (H, W, 3))
+        _lib.check(_lib.lib().pysp_demosaic_dev(ctx.handle, src.ptr, H, W, _lib.wb3(wb), M, quality, int(bool(image.get_hdr())), int(stages), rgb.ptr))
+        rgb._keepalive = bayer          # the upload is only enqueued: the mosaic must outlive it
+        src.release()                   # back to the context's cache; stream order protects it until the kernels are done
+    else:
+        rgb = np.empty((H, W, 3), np.float32)
+        _lib.check(_lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(bayer), H, W, _lib.wb3(wb), M, quality,
+                                                int(bool(image.get_hdr())), int(stages), _lib.ptr(rgb)))
     out = RawDemosaicData(rgb, wb, wb_norm=False)
     out.mat_xyz = mat
     out.current_ev = image.current_ev

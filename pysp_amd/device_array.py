@@ -1,0 +1,153 @@
+"""Lazily materialised arrays: results of the drop-in classes stay in HBM until somebody reads them.
+
+`RawRggbBayerData.demosaic(...)` leaves the demosaiced image on the GPU, `RawDemosaicData.to_lin_srgb()` returns a
+`DeviceArray`, and `lin_srgb_to_srgb(DeviceArray)` downloads once at the end -- the README recipe (README.md:55-63 of the
+reference) costs one upload, its kernels and one download instead of three round trips.
+
+A DeviceArray quacks like the float32 ndarray the reference returns: `np.asarray(x)` (or any NumPy function, arithmetic,
+indexing, attribute access) materialises it once and caches the host copy.  It is NOT an ndarray instance; code that needs
+`isinstance(x, np.ndarray)` calls `np.asarray(x)` first, or switches laziness off with `pysp_amd.set_lazy(False)`
+(environment: PYSP_EAGER=1), after which every call returns plain ndarrays exactly like the reference.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_lazy = os.environ.get("PYSP_EAGER", "0") in ("", "0")
+
+
+def set_lazy(on: bool) -> None:
+    global _lazy
+    _lazy = bool(on)
+
+
+def lazy_enabled() -> bool:
+    return _lazy
+
+
+class DeviceArray:
+    """A C-contiguous float32 array that lives in a device buffer of a pysp context (see module docstring)."""
+
+    __array_priority__ = 100.0
+
+    def __init__(self, ctx: "_lib.Context", shape: Tuple[int, ...], dptr: Optional[int] = None):
+        self._ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(np.float32)
+        self._host: Optional[np.ndarray] = None
+        self._keepalive = None          # host data an enqueued upload / kernel chain still reads; dropped at the first synchronising call
+        n = self.nbytes
+        if dptr is None:
+            dptr = _lib.lib().pysp_dev_alloc(ctx.handle, ctypes.c_size_t(n))
+            if not dptr:
+                raise MemoryError(_lib.last_error())
+        self._ptr: Optional[int] = int(dptr)
+
+    # ---- construction / destruction
+    @classmethod
+    def from_host(cls, ctx, a: np.ndarray) -> "DeviceArray":
+        a = _lib.f32c(a)
+        out = cls(ctx, a.shape)
+        _lib.check(_lib.lib().pysp_dev_upload(ctx.handle, out.ptr, _lib.ptr(a), ctypes.c_size_t(a.nbytes)))
+        out._keepalive = a          # the upload is enqueued: the source must outlive it (released at the first synchronising call)
+        return out
+
+    def release(self) -> None:
+        if getattr(self, "_ptr", None):
+            try:
+                _lib.lib().pysp_dev_free(self._ctx.handle, ctypes.c_void_p(self._ptr))
+            except Exception:
+                pass
+            self._ptr = None
+
+    def __del__(self):
+        self.release()
+
+    # ---- device side
+    @property
+    def ptr(self) -> ctypes.c_void_p:
+        if not self._ptr:
+            raise ValueError("the device copy of this array has been released")
+        return ctypes.c_void_p(self._ptr)
+
+    @property
+    def on_device(self) -> bool:
+        return bool(self._ptr)
+
+    @property
+    def context(self):
+        return self._ctx
+
+    # ---- host side
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self) -> int:
+        return self.size * 4
+
+    def numpy(self) -> np.ndarray:
+        """The host copy (downloaded on first use, cached)."""
+        if self._host is None:
+            out = np.empty(self.shape, np.float32)
+            _lib.check(_lib.lib().pysp_dev_download(self._ctx.handle, _lib.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
+            self._host = out
+            self._keepalive = None
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, k):
+        return self.numpy()[k]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, float32, {'on device' if self._ptr else 'released'}{', host copy cached' if self._host is not None else ''})"
+
+    def __getattr__(self, name):        # anything else an ndarray offers (astype, reshape, mean, flags, T, ...)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
+
+def _delegate(name):
+    def op(self, *args):
+        return getattr(self.numpy(), name)(*[a.numpy() if isinstance(a, DeviceArray) else a for a in args])
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "mod", "matmul", "and", "or", "xor", "lshift", "rshift"):
+    setattr(DeviceArray, f"__{_n}__", _delegate(f"__{_n}__"))
+    setattr(DeviceArray, f"__r{_n}__", _delegate(f"__r{_n}__"))
+for _n in ("neg", "pos", "abs", "lt", "le", "gt", "ge", "eq", "ne", "bool", "float", "int"):
+    setattr(DeviceArray, f"__{_n}__", _delegate(f"__{_n}__"))
+DeviceArray.__hash__ = None
+
+
+def as_device(x, ctx=None) -> DeviceArray:
+    """x as a DeviceArray on `ctx` (default context): DeviceArrays of that context pass through, host data is uploaded."""
+    ctx = ctx or _lib.default_context()
+    if isinstance(x, DeviceArray) and x.on_device and x.context is ctx:
+        return x
+    return DeviceArray.from_host(ctx, np.asarray(x))

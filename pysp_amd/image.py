@@ -36,7 +36,8 @@ class RawRggbBayerData(RawRggbBayerData_BaseType):
             out = debayer_fast(self)
         else:
             raise NotImplementedError("Quality mode not implemented: %s" % str(quality))
-        out.image = reversible_transform_rggb(out.image, self.source_pattern)   # a view, like the reference
+        if self.source_pattern != BayerPattern.Rggb:      # RGGB: identity -- and reading out.image would download a result that may never be needed on the host
+            out.image = reversible_transform_rggb(out.image, self.source_pattern)   # a view, like the reference
         return out
 
     debayer = demosaic          # README.md:62 spelling

@@ -300,3 +300,74 @@ def test_srgb_curve_exhaustive(orc):
     assert np.array_equal(lin_srgb_to_srgb(neg.reshape(1, -1, 1).repeat(3, axis=2)), np.zeros((1, 4, 3), np.float32))
     print(f"sRGB curve: {n} inputs, {differ} differ from the oracle, worst {worst} ULP")
     assert n > 1_065_353_216 and differ == 0, (n, differ, worst)
+
+
+# ---- device-resident drop-in objects; overlapped host pipeline ------------------------------------------
+def test_readme_recipe_stays_on_the_gpu_until_read(orc, wbobj):
+    """README.md:55-63: demosaic(...).to_lin_srgb() then lin_srgb_to_srgb(...).  The intermediates are lazy DeviceArrays:
+    one upload, the kernels, one download; results identical to the eager (ndarray everywhere) mode and to the oracle."""
+    import pysp_amd
+    from pysp_amd import DeviceArray
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    bay = rggb_frame(300, 412, 77)
+    ref_rgb = orc.demosaic_ahd(bay, wb, M, False, 1)
+    ref_srgb = orc.pipeline_srgb(bay, wb, M, 2, False, 1, False)
+    assert pysp_amd.lazy_enabled()
+    dem = RawRggbBayerData(bay, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Best, 1)
+    assert dem._dev is not None and dem._img is None and dem.is_valid()          # nothing downloaded yet
+    lin = dem.to_lin_srgb()
+    assert isinstance(lin, DeviceArray) and lin.on_device and lin._host is None and lin.shape == (300, 412, 3) and lin.dtype == np.float32
+    assert dem._dev is not None                                                  # to_lin_srgb did not pull the image down either
+    srgb = lin_srgb_to_srgb(lin)
+    assert isinstance(srgb, np.ndarray) and srgb.dtype == np.float32 and ulp_diff(srgb, ref_srgb).max() == 0
+    assert lin._host is None                                                     # still only on the GPU
+    # reading .image downloads once; from then on it is an ordinary ndarray attribute the caller may edit in place
+    img = dem.image
+    assert isinstance(img, np.ndarray) and np.array_equal(img, ref_rgb) and dem._dev is None and dem.image is img
+    img[0, 0, 0] = 0.5
+    assert np.array_equal(dem.to_lin_srgb()[0, 0], orc.cam_to_rgb(img[:1, :1], M, True)[0, 0])     # the edit is what gets coloured
+    # the lazy array quacks like the ndarray of the reference
+    assert np.array_equal(np.asarray(lin), orc.cam_to_rgb(ref_rgb, M, True)) and lin._host is not None
+    assert np.array_equal(lin / (1 + lin), np.asarray(lin) / (1 + np.asarray(lin))) and lin[3, 4, 1] == np.asarray(lin)[3, 4, 1]
+    assert lin.mean() == np.asarray(lin).mean() and lin.astype(np.float64).dtype == np.float64 and len(lin) == 300
+    # eager mode: plain ndarrays everywhere, same numbers
+    pysp_amd.set_lazy(False)
+    try:
+        dem2 = RawRggbBayerData(bay, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Best, 1)
+        lin2 = dem2.to_lin_srgb()
+        assert isinstance(dem2._img, np.ndarray) and isinstance(lin2, np.ndarray)
+        assert np.array_equal(dem2.image, ref_rgb) and np.array_equal(lin_srgb_to_srgb(lin2), srgb)
+    finally:
+        pysp_amd.set_lazy(True)
+
+
+def test_host_pipeline_in_overlapped_bands_equals_whole_frame(orc, wbobj):
+    """The host-buffer entry points cut frames of more than 4 MP into 512-row bands (upload / kernels / download overlap):
+    same bits as the device-resident whole-frame call, for every quality, the HDR metric, stages 0..3 and uint16 input."""
+    import ctypes
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    L, ctx = _lib.lib(), _lib.default_context()
+    pipe = DevicePipeline(0)
+    H, W = 2230, 2054                                  # 4.6 MP: 5 bands, the last one short; W % 4 == 2 exercises the unstaged store path
+    bay = rggb_frame(H, W, 31)
+    d = torch.from_numpy(bay).cuda()
+    out = np.empty((H, W, 3), np.float32)
+    for q, hdr, stages, rh in ((0, 0, 0, 0), (1, 0, 0, 0), (2, 0, 0, 0), (2, 0, 1, 0), (2, 1, 1, 1), (2, 0, 3, 0)):
+        _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, _lib.wb3(wb), _lib.mat9(M), q, hdr, stages, rh, _lib.ptr(out)))
+        want = pipe.demosaic_to_srgb(d, wb, M, q, bool(hdr), stages, bool(rh)).cpu().numpy()
+        assert np.array_equal(out, want), (q, hdr, stages, rh)
+    _lib.check(L.pysp_demosaic_f32(ctx.handle, _lib.ptr(bay), H, W, _lib.wb3(wb), _lib.mat9(M), 2, 0, 1, _lib.ptr(out)))
+    assert np.array_equal(out, pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, False, 1).cpu().numpy())
+    raw = (np.random.default_rng(4).random((H, W)) * 16383).astype(np.uint16)
+    black, sat = (ctypes.c_float * 4)(500, 510, 520, 505), (ctypes.c_float * 4)(15000, 15100, 14900, 15050)
+    _lib.check(L.pysp_pipeline_u16_f32(ctx.handle, _lib.ptr(raw), H, W, black, sat, _lib.wb3(wb), _lib.mat9(M), 2, 0, 1, 2, _lib.ptr(out)))
+    want = pipe.raw_u16_to_rgb(torch.from_numpy(raw.view(np.int16)).cuda(), list(black), list(sat), wb, M, _lib.QUALITY_BEST, 1, 2).cpu().numpy()
+    assert np.array_equal(out, want)
