@@ -83,6 +83,11 @@ void *pysp_dev_alloc(pysp_ctx *ctx, size_t bytes);
 int pysp_dev_free(pysp_ctx *ctx, void *dptr);
 int pysp_dev_upload(pysp_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int pysp_dev_download(pysp_ctx *ctx, void *host, const void *dptr, size_t bytes);
+/* Page-locked host memory (hipHostMalloc / hipHostFree).  Host entry points accept any host pointer; buffers from here make
+ * their copies asynchronous DMA (the overlapped bands of pysp_pipeline_* need that to overlap) and avoid first-touch page
+ * faults in freshly allocated result arrays.  The Python wrapper hands out its result arrays from a pool of these. */
+void *pysp_host_alloc(size_t bytes);
+int pysp_host_free(void *p);
 
 /* ---- Bayer plane helpers -------------------------------------------------------------------- */
 /* bayer_chan_mixer.py:4-21 bayer_to_rgbg (float32 or uint16 mosaic -> four float32 quarter planes) */

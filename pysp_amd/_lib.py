@@ -46,6 +46,8 @@ _SIGNATURES = {
     "pysp_dev_free": (_int, [_vp, _vp]),
     "pysp_dev_upload": (_int, [_vp, _vp, _vp, _sz]),
     "pysp_dev_download": (_int, [_vp, _vp, _vp, _sz]),
+    "pysp_host_alloc": (_vp, [_sz]),
+    "pysp_host_free": (_int, [_vp]),
     "pysp_wb_scale_dev": (_int, [_vp, _vp, _sz, _f32p, _int, _vp]),
     "pysp_bayer_to_rgbg_f32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pysp_bayer_to_rgbg_u16": (_int, [_vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
@@ -236,6 +238,12 @@ def default_context() -> Context:
 # ---- small marshalling helpers -----------------------------------------------------------------
 def ptr(a: np.ndarray) -> ctypes.c_void_p:
     return ctypes.c_void_p(a.ctypes.data)
+
+
+def empty_f32(shape) -> np.ndarray:
+    """np.empty(shape, float32) for results: large ones come from the page-locked pool (see _hostpool.py)."""
+    from . import _hostpool
+    return _hostpool.empty(shape, np.float32)
 
 
 def f32c(a) -> np.ndarray:

@@ -49,7 +49,7 @@ def cam_to_rgb_norm(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, destination
         _lib.check(_lib.lib().pysp_cam_to_rgb_dev(rgb.context.handle, rgb.ptr, rgb.size // 3, _lib.mat9(M), int(bool(clip_highlights)), out.ptr))
         return out
     a = _rgb_image(rgb)
-    out = np.empty_like(a)
+    out = _lib.empty_f32(a.shape)
     _lib.check(_lib.lib().pysp_cam_to_rgb_f32(_lib.default_context().handle, _lib.ptr(a), a.size // 3, _lib.mat9(M),
                                               int(bool(clip_highlights)), _lib.ptr(out)))
     return out
@@ -71,7 +71,7 @@ def cam_to_clean_xyz(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, pcs_colors
 
 def _flat(fn_name: str, x: np.ndarray) -> np.ndarray:
     a = _lib.f32c(x)
-    out = np.empty_like(a)
+    out = _lib.empty_f32(a.shape)
     _lib.check(getattr(_lib.lib(), fn_name)(_lib.default_context().handle, _lib.ptr(a), ctypes.c_size_t(a.size), _lib.ptr(out)))
     return out
 

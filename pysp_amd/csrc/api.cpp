@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -295,6 +296,20 @@ int pysp_dev_download(pysp_ctx* ctx, void* host, const void* dptr, size_t bytes)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PYSP_OK;
 }
+// Page-locked host memory: results handed back to Python come from a pool of these (pysp_amd/_hostpool.py), so a download is
+// one DMA at link speed into pages that are already resident -- a fresh 288 MB np.empty costs ~20 ms of page faults on top
+// of the 5 ms copy -- and the banded host pipeline's device-to-host leg really runs beside the next band's upload.
+void* pysp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(PYSP_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+int pysp_host_free(void* p) {
+    if (!p) return PYSP_OK;
+    HIP_TRY(hipHostFree(p));
+    return PYSP_OK;
+}
 int pysp_wb_scale_dev(pysp_ctx* ctx, const float* d_in, size_t npx, const float coeff[3], int undo, float* d_out) {
     CTX_ENTER(ctx);
     if (!d_in || !d_out || !coeff) return fail(PYSP_EBADARG, "wb_scale: null pointer");
@@ -494,7 +509,8 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     if (quality < PYSP_QUALITY_DRAFT || quality > PYSP_QUALITY_BEST) return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
     const int st = stages < 0 ? 0 : stages;
     const int halo = 8 + 4 * st;
-    int band = 512;                                              // output rows per band (even)
+    static const int band_env = [] { const char* e = getenv("PYSP_BAND_ROWS"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 1) & ~1 : 0; }();
+    int band = band_env ? band_env : 256;                        // output rows per band (even; measured at 24 MP: 128 rows 6.13 ms, 256 5.94, 512 6.00, 1024 6.20 per fused call); PYSP_BAND_ROWS overrides
     const size_t px = (size_t)H * W;
     int nb = px < ((size_t)1 << 22) ? 1 : (H + band - 1) / band;  // small frames: one piece
     if (nb < 2) { nb = 1; band = H; }

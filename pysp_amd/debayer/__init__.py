@@ -30,7 +30,7 @@ def _run(image: RawRggbBayerData_BaseType, quality: int, stages: int = 0) -> Raw
         rgb._keepalive = bayer          # the upload is only enqueued: the mosaic must outlive it
         src.release()                   # back to the context's cache; stream order protects it until the kernels are done
     else:
-        rgb = np.empty((H, W, 3), np.float32)
+        rgb = _lib.empty_f32((H, W, 3))
         _lib.check(_lib.lib().pysp_demosaic_f32(_lib.default_context().handle, _lib.ptr(bayer), H, W, _lib.wb3(wb), M, quality,
                                                 int(bool(image.get_hdr())), int(stages), _lib.ptr(rgb)))
     out = RawDemosaicData(rgb, wb, wb_norm=False)

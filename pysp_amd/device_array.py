@@ -100,7 +100,7 @@ class DeviceArray:
     def numpy(self) -> np.ndarray:
         """The host copy (downloaded on first use, cached)."""
         if self._host is None:
-            out = np.empty(self.shape, np.float32)
+            out = _lib.empty_f32(self.shape)
             _lib.check(_lib.lib().pysp_dev_download(self._ctx.handle, _lib.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
             self._host = out
             self._keepalive = None

@@ -346,7 +346,7 @@ def test_readme_recipe_stays_on_the_gpu_until_read(orc, wbobj):
 
 
 def test_host_pipeline_in_overlapped_bands_equals_whole_frame(orc, wbobj):
-    """The host-buffer entry points cut frames of more than 4 MP into 512-row bands (upload / kernels / download overlap):
+    """The host-buffer entry points cut frames of more than 4 MP into 256-row bands (upload / kernels / download overlap):
     same bits as the device-resident whole-frame call, for every quality, the HDR metric, stages 0..3 and uint16 input."""
     import ctypes
     import torch
@@ -356,7 +356,7 @@ def test_host_pipeline_in_overlapped_bands_equals_whole_frame(orc, wbobj):
     wb, M = _wbM(orc)
     L, ctx = _lib.lib(), _lib.default_context()
     pipe = DevicePipeline(0)
-    H, W = 2230, 2054                                  # 4.6 MP: 5 bands, the last one short; W % 4 == 2 exercises the unstaged store path
+    H, W = 2230, 2054                                  # 4.6 MP: 9 bands, the last one short; W % 4 == 2 exercises the unstaged store path
     bay = rggb_frame(H, W, 31)
     d = torch.from_numpy(bay).cuda()
     out = np.empty((H, W, 3), np.float32)

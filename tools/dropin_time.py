@@ -13,7 +13,7 @@ from pysp_amd.synth import default_wb, rggb_frame
 H, W = 4000, 6000
 bay = rggb_frame(H, W, 1000)
 wbobj = default_wb()
-for it in range(3):
+for it in range(8):
     t0 = time.perf_counter()
     raw = RawRggbBayerData(bay, wbobj, 10.0, 1.0)
     lin = raw.demosaic(QualityDemosaic.Best).to_lin_srgb()
@@ -23,13 +23,21 @@ for it in range(3):
     print("README recipe: demosaic+to_lin_srgb %.1f ms, lin_srgb_to_srgb %.1f ms, total %.1f ms = %.2f GMP/s" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3, H * W / 1e9 / (t2 - t0)))
 L = _lib.lib(); ctx = _lib.default_context()
 wb = _lib.wb3(wbobj.get_reciprocal_multipliers()); M = _lib.mat9(final_matrix(wbobj.get_matrix()))
-out = np.empty((H, W, 3), np.float32)
-for it in range(4):
+out = _lib.empty_f32((H, W, 3))          # page-locked result buffer, as the Python wrappers use
+ts = []
+for it in range(12):
     t0 = time.perf_counter()
     _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, wb, M, 2, 0, 1, 0, _lib.ptr(out)))
-    t1 = time.perf_counter()
-    print("one fused call (host buffers): %.1f ms = %.2f GMP/s, kernels %.2f ms" % ((t1 - t0) * 1e3, H * W / 1e9 / (t1 - t0), ctx.last_kernel_ms()))
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("one fused call (host buffers, pinned result): first %.1f ms, then min %.2f / median %.2f / max %.2f ms = %.2f GMP/s at the median" % (ts[0], min(ts[1:]), sorted(ts[1:])[len(ts) // 2], max(ts[1:]), H * W / 1e6 / sorted(ts[1:])[len(ts) // 2]))
 assert np.array_equal(out, srgb)
+pag_out = np.empty((H, W, 3), np.float32); pag_out[:] = 0
+ts = []
+for it in range(12):
+    t0 = time.perf_counter()
+    _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, wb, M, 2, 0, 1, 0, _lib.ptr(pag_out)))
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("one fused call (host buffers, pageable result): min %.2f / median %.2f / max %.2f ms" % (min(ts[1:]), sorted(ts[1:])[len(ts) // 2], max(ts[1:])))
 # raw copy rates
 d = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
 pin = torch.empty(H * W * 3, dtype=torch.float32).pin_memory()
