@@ -74,6 +74,8 @@ def parse_args(argv=None):
                          "stretch each other, so per-kernel durations (rocprofv3's, too) stop meaning anything; the default keeps them clean")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo rehearses the N > 1 path with host-staged collectives, ranks may share a GPU)")
+    ap.add_argument("--lab-mode", default="cv410_lut", choices=["closed_form", "cv410_lut"],
+                    help="restatement of cv2.cvtColor(RGB2LAB) behind AHD's homogeneity vote (pysp_ctx_set_lab_mode)")
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
     ap.add_argument("--settle", type=float, default=0.4,
                     help="seconds of untimed steps run BEFORE the W warmup steps so that the clocks have reached their loaded state when a short "
@@ -154,6 +156,8 @@ def main() -> None:
     n_streams = max(1, args.streams) if args.workload not in ("cfg3", "cfg5") else 1
     ctxs = [_lib.Context(dev_index) for _ in range(n_streams)]   # own HIP streams; kernels are timed with events on THOSE streams
     ctx = ctxs[0]
+    for c in ctxs:
+        c.set_lab_mode(args.lab_mode)
     L = _lib.lib()
     alg_bytes_per_px = ALG_BYTES_PER_PX
     frames_per_step = 1
@@ -179,6 +183,7 @@ def main() -> None:
         from pysp_amd.multi_gpu import PHASES, BandPlan, demosaic_warp_banded_dev
         from pysp_amd.pipeline import DevicePipeline
         pipe = DevicePipeline(dev_index)
+        pipe.ctx.set_lab_mode(args.lab_mode)
         kernel_ctx = pipe.ctx
         scaling = "strong"
         plan = BandPlan(H, W, world, rank, stages)
@@ -421,7 +426,7 @@ def main() -> None:
         except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
             cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc}"}
 
-    cfg = {"workload": desc, "H": H, "W": W, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
+    cfg = {"workload": desc, "H": H, "W": W, "lab_mode": args.lab_mode, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
            "backend": ("rccl" if args.backend == "nccl" else "gloo") if dist is not None else None,
            "untimed_settle_steps": settle_steps,
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"

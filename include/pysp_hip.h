@@ -64,6 +64,15 @@ void *pysp_ctx_get_stream(pysp_ctx *ctx);
  * 321x4 floats (sRGB decode, v in [2^-5,1]), cb 257x4 floats (cube root, t in [2^-7,2)).  Host only, needs no
  * GPU; exported so that tests can compare the tables with the CPU oracle's bit for bit. */
 int pysp_lab_tables(float *dec, float *cb);
+/* Which restatement of cv2.cvtColor(COLOR_RGB2LAB) (debayer/ahd.py:58,62) the AHD homogeneity metric of this context uses:
+ *   1 (default) OpenCV 4.10's default float32 path: 33^3 int16 grid, fixed-point trilinear interpolation (14-bit), output
+ *               quantised to 100/2^14 (L) and 1/64 (a, b) -- what opencv_python==4.10.0.84 is believed to run;
+ *   0           closed form: sRGB decode + D65 CIELab with the table-driven pow / cbrt above (round 1's metric; 5 % faster).
+ * Neither can be pinned without cv2; they differ in 2.7 % of the H/V decisions of the benchmark frame.
+ * pysp_lab_cv410_lut writes the 33*33*33*3 int16 grid of mode 1 ([B][G][R] point order; host only, no GPU needed). */
+int pysp_ctx_set_lab_mode(pysp_ctx *ctx, int mode);
+int pysp_ctx_get_lab_mode(pysp_ctx *ctx);
+int pysp_lab_cv410_lut(int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
  * the context's stream; waits for completion). */

@@ -9,9 +9,9 @@ order), in plain NumPy float32, independently of oracle/pysp_oracle.c, so that
     edge_assisted_gaussian.py, fast_resize.py) with this module standing in for `cv2`
     (fixtures produced that way carry "cv2_restated": true).
 cvtColor(RGB2LAB) exists twice, both in NumPy with no call into the C oracle:
-  * LAB_MODE = "closed_form" (default): sRGB decode + D65 CIELab with table-driven pow / cbrt, the arithmetic
-    the product kernels and oracle/pysp_oracle.c::rgb2lab_px follow bit for bit (tables rebuilt here from libm);
-  * LAB_MODE = "cv410_lut": OpenCV 4.10's default float32 path for sRGB input as published in
+  * LAB_MODE = "closed_form": sRGB decode + D65 CIELab with table-driven pow / cbrt, the arithmetic of lab mode 0 of
+    the product kernels and of oracle/pysp_oracle.c::rgb2lab_px, bit for bit (tables rebuilt here from libm);
+  * LAB_MODE = "cv410_lut" (default since round 2, lab mode 1): OpenCV 4.10's default float32 path for sRGB input as published in
     modules/imgproc/src/color_lab.cpp (RGB2Lab_f with useInterpolation): clip, cvRound(v * 2^14), 33^3 int16
     LUT of closed-form Lab at the grid points, fixed-point trilinear interpolation, rescale.  Restated FROM
     MEMORY of that source (unpinnable here); tests/lab_flip_rate.py reports how many AHD decisions differ
@@ -76,7 +76,7 @@ def filter2D(src, ddepth, kernel):
 
 
 # ---- cvtColor(COLOR_RGB2LAB), float32 (ahd.py:58,62) ------------------------------------------------------------
-LAB_MODE = "closed_form"          # or "cv410_lut"; tests/golden/gen_golden.py runs with the default
+LAB_MODE = "cv410_lut"            # or "closed_form"; tests/golden/gen_golden.py runs with the default
 
 
 def _fmaf(a, b, c):

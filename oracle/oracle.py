@@ -166,9 +166,12 @@ def rgb2lab(rgb: np.ndarray) -> np.ndarray:
     return out
 
 
+DEFAULT_LAB_MODE = 1     # like the product's contexts (pysp_ctx_set_lab_mode) and oracle/cv2_restated.py::LAB_MODE
+
+
 def set_lab_mode(mode: int) -> None:
-    """0: closed-form Lab with table-driven pow / cbrt (what the product computes); 1: the OpenCV 4.10 LUT + trilinear
-    restatement.  Process-wide switch of the oracle; used by tests/lab_flip_rate.py and the Lab tests only."""
+    """1 (default): the OpenCV 4.10 LUT + trilinear restatement; 0: closed-form Lab with table-driven pow / cbrt.
+    Process-wide switch of the oracle; tests that change it restore DEFAULT_LAB_MODE."""
     _chk(lib().orc_set_lab_mode(int(mode)), "set_lab_mode")
 
 

@@ -148,9 +148,11 @@ static void lab_build(float (*tab)[4], int n, int nb, int loexp, double (*fn)(do
         tab[i][3] = (float)x0;   /* segment start, = x with its low S bits cleared for every x of the segment */
     }
 }
+static void cv410_build(void);
 __attribute__((constructor)) static void lab_tables_init(void) {
     lab_build(lab_dec_tab, LAB_DEC_N, LAB_DEC_NB, LAB_DEC_LOEXP, lab_dec_fn);
     lab_build(lab_cb_tab, LAB_CB_N, LAB_CB_NB, LAB_CB_LOEXP, lab_cb_fn);
+    cv410_build();
 }
 static inline float lab_lut(float (*tab)[4], int nb, int loexp, float x) {
     int s = 23 - nb;
@@ -202,9 +204,10 @@ static inline void rgb2lab_px(float R, float G, float B, float *L, float *a, flo
  *   interpolation in fixed point (cell = iv >> 9, position in the cell = (iv >> 5) & 15, weights = products of three
  *   4-bit factors, CV_DESCALE by 12 bits) -> L = l*100/2^14, a = a'*256/2^14 - 128, b likewise.
  * Output is therefore quantised (L in steps of 100/16384, a and b in steps of 1/64).  orc_set_lab_mode(1) makes
- * every Lab conversion of this library (orc_rgb2lab and the AHD homogeneity metric) use it; tests/lab_flip_rate.py
- * measures how many H/V decisions that changes.  The product follows mode 0. */
-static int g_lab_mode = 0;
+ * every Lab conversion of this library (orc_rgb2lab and the AHD homogeneity metric) use it -- the DEFAULT since round 2, in the
+ * oracle as in the product (pysp_ctx_set_lab_mode); mode 0 is the closed form.  tests/lab_flip_rate.py measures how many H/V
+ * decisions the choice changes. */
+static int g_lab_mode = 1;   /* default: the OpenCV 4.10 path, like the product (mode 0 = the closed form of round 1) */
 static int16_t cv410_lut[33][33][33][3];   /* [B][G][R] grid point */
 static int cv410_ready = 0;
 static void cv410_build(void) {

@@ -36,6 +36,9 @@ _SIGNATURES = {
     "pysp_ctx_create": (_vp, [_int, _vp]),
     "pysp_ctx_destroy": (None, [_vp]),
     "pysp_ctx_sync": (_int, [_vp]),
+    "pysp_ctx_set_lab_mode": (_int, [_vp, _int]),
+    "pysp_ctx_get_lab_mode": (_int, [_vp]),
+    "pysp_lab_cv410_lut": (_int, [_vp]),
     "pysp_ctx_set_stream": (_int, [_vp, _vp]),
     "pysp_ctx_get_stream": (_vp, [_vp]),
     "pysp_lab_tables": (_int, [_f32p, _f32p]),
@@ -163,6 +166,8 @@ class Context:
         if not self._h:
             raise RuntimeError(f"pysp_ctx_create failed: {last_error()}")
         self.device = int(device)
+        if os.environ.get("PYSP_LAB_MODE", "") in ("0", "closed_form"):      # default is 1, the OpenCV 4.10 LUT path
+            self.set_lab_mode(0)
 
     @property
     def handle(self):
@@ -170,6 +175,14 @@ class Context:
 
     def sync(self) -> None:
         check(lib().pysp_ctx_sync(self.handle))
+
+    def set_lab_mode(self, mode) -> None:
+        """AHD's Lab restatement: 1 / "cv410_lut" (default: OpenCV 4.10's LUT + trilinear path) or 0 / "closed_form"."""
+        mode = {"closed_form": 0, "cv410_lut": 1, "cv410": 1}.get(mode, mode)
+        check(lib().pysp_ctx_set_lab_mode(self.handle, int(mode)))
+
+    def get_lab_mode(self) -> int:
+        return int(lib().pysp_ctx_get_lab_mode(self.handle))
 
     def set_stream(self, stream: int) -> None:
         """Bind to a caller-owned hipStream_t (0 = the device's default stream), e.g. torch's current stream."""

@@ -61,6 +61,8 @@ struct pysp_ctx {
     size_t cap[NSLOT] = {};
     float* lanczos = nullptr;
     float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
+    int lab_mode = 1;            // 1 (default): OpenCV 4.10's LUT + trilinear restatement; 0: closed-form Lab (tables above)
+    void* lablut = nullptr;      // mode 1: [34][34][34] x 16 B grid (devmath.h)
     Timeline tl;
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
     hipStream_t copy_stream = nullptr;
@@ -136,9 +138,58 @@ void host_lab_slots(float* slots) {
         memcpy(slots + 4 * (LAB_DEC_SLOTS + ((((127 + LAB_CB_LOEXP) << LAB_CB_NB) + i) & (LAB_CB_SLOTS - 1))), &cb[4 * i], 16);
 }
 
+// OpenCV 4.10 RGB2Lab grid (color_lab.cpp initLabTabs, restated): 33^3 points, closed-form Lab of applyGamma(p/32) in float32
+// arithmetic (softfloat there), scaled to 14 bits and rounded; [B][G][R] order, (L, a, b) per point.
+void host_cv410_lut(int16_t* out /* 33*33*33*3 */) {
+    static const double white[3] = {0.950456, 1.0, 1.088754};
+    static const double xyz[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    float C[9], gam[33];
+    for (int i = 0; i < 9; i++) C[i] = (float)((i / 3 == 1 ? 1.0 : 1.0 / white[i / 3]) * xyz[i]);
+    for (int p = 0; p < 33; p++) {
+        float x = (float)p / 32.0f;
+        gam[p] = x <= 0.04045f ? x / 12.92f : (float)pow((double)((x + 0.055f) / 1.055f), 2.4);
+    }
+    const float lthresh = 216.0f / 24389.0f, lscale = 841.0f / 108.0f, lbias = 16.0f / 116.0f, kap = 24389.0f / 27.0f;
+    auto f = [&](float t) { return t > lthresh ? (float)cbrt((double)t) : fmaf(t, lscale, lbias); };
+    for (int r = 0; r < 33; r++)
+        for (int q = 0; q < 33; q++)
+            for (int p = 0; p < 33; p++) {
+                volatile float R = gam[p], G = gam[q], B = gam[r];          // volatile: every product and sum rounds to float32 (host compilers may contract)
+                volatile float x0 = R * C[0], x1 = G * C[1], x2 = B * C[2], y0 = R * C[3], y1 = G * C[4], y2 = B * C[5], z0 = R * C[6], z1 = G * C[7], z2 = B * C[8];
+                volatile float xs = x0 + x1, ys = y0 + y1, zs = z0 + z1;
+                volatile float X = xs + x2, Y = ys + y2, Z = zs + z2;
+                float FX = f(X), FY = f(Y), FZ = f(Z);
+                volatile float l1 = 116.0f * FY, l2 = kap * Y, dxy = FX - FY, dyz = FY - FZ;
+                volatile float L = Y > lthresh ? l1 - 16.0f : l2, a = 500.0f * dxy, b = 200.0f * dyz;
+                volatile float sL = 16384.0f * L, ap = a + 128.0f, bp = b + 128.0f;
+                volatile float sa = 16384.0f * ap, sb = 16384.0f * bp;
+                int16_t* o = out + ((size_t)(r * 33 + q) * 33 + p) * 3;
+                o[0] = (int16_t)lrintf(sL / 100.0f); o[1] = (int16_t)lrintf(sa / 256.0f); o[2] = (int16_t)lrintf(sb / 256.0f);
+            }
+}
+// device layout of devmath.h::rgb2lab_cv410
+static void host_cv410_device_lut(std::vector<int16_t>& dev) {
+    std::vector<int16_t> lut(33 * 33 * 33 * 3);
+    host_cv410_lut(lut.data());
+    const int D = 34;
+    dev.assign((size_t)D * D * D * 8, 0);
+    auto at = [&](int z, int y, int x, int c) { z = z > 32 ? 32 : z; y = y > 32 ? 32 : y; x = x > 32 ? 32 : x; return lut[((size_t)(z * 33 + y) * 33 + x) * 3 + c]; };
+    for (int z = 0; z < D; z++)
+        for (int y = 0; y < D; y++)
+            for (int x = 0; x < D; x++) {
+                int16_t* e = &dev[(((size_t)z * D + y) * D + x) * 8];
+                for (int c = 0; c < 3; c++) { e[2 * c] = at(z, y, x, c); e[2 * c + 1] = at(z, y, x + 1, c); }
+            }
+}
+
 extern "C" {
 
 int pysp_abi_version(void) { return PYSP_ABI_VERSION; }
+int pysp_lab_cv410_lut(int16_t* out) {
+    if (!out) return fail(PYSP_EBADARG, "pysp_lab_cv410_lut: null output");
+    host_cv410_lut(out);
+    return PYSP_OK;
+}
 const char* pysp_last_error(void) { return g_err; }
 
 int pysp_device_count(void) {
@@ -178,6 +229,12 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
     host_lab_slots(lt.data());
     if (hipMalloc(reinterpret_cast<void**>(&c->labtab), lt.size() * sizeof(float)) != hipSuccess ||
         hipMemcpy(c->labtab, lt.data(), lt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "Lab table upload failed"); pysp_ctx_destroy(c); return nullptr; }
+    {
+        std::vector<int16_t> dev;
+        host_cv410_device_lut(dev);
+        if (hipMalloc(&c->lablut, dev.size() * sizeof(int16_t)) != hipSuccess ||
+            hipMemcpy(c->lablut, dev.data(), dev.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "Lab grid upload failed"); pysp_ctx_destroy(c); return nullptr; }
+    }
     return c;
 }
 
@@ -192,6 +249,7 @@ void pysp_ctx_destroy(pysp_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->ev_done[i]) { e = hipEventDestroy(c->ev_done[i]); (void)e; }
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
     if (c->labtab) { e = hipFree(c->labtab); (void)e; }
+    if (c->lablut) { e = hipFree(c->lablut); (void)e; }
     for (int i = 0; i < 2 * Timeline::MAXK; i++) if (c->tl.ev[i]) { e = hipEventDestroy(c->tl.ev[i]); (void)e; }
     if (c->ev0) { e = hipEventDestroy(c->ev0); (void)e; }
     if (c->ev1) { e = hipEventDestroy(c->ev1); (void)e; }
@@ -204,6 +262,14 @@ int pysp_ctx_sync(pysp_ctx* ctx) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PYSP_OK;
 }
+
+int pysp_ctx_set_lab_mode(pysp_ctx* ctx, int mode) {
+    CTX_ENTER(ctx);
+    if (mode != 0 && mode != 1) return fail(PYSP_EBADARG, "lab mode must be 0 (closed form) or 1 (OpenCV 4.10 LUT + trilinear)");
+    ctx->lab_mode = mode;
+    return PYSP_OK;
+}
+int pysp_ctx_get_lab_mode(pysp_ctx* ctx) { return ctx ? ctx->lab_mode : -1; }
 
 int pysp_ctx_set_stream(pysp_ctx* ctx, void* stream) {
     CTX_ENTER(ctx);
@@ -479,7 +545,7 @@ static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, c
         size_t bytes = (size_t)H * W * 12;
         if (stages >= 1) RESERVE(ctx, S_TMP0, bytes, t0);
         if (stages >= 2) RESERVE(ctx, S_TMP1, bytes, t1);
-        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, &ctx->tl));
+        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl));
     } else if (quality == PYSP_QUALITY_FAST) {
         LAUNCH_TRY(launch_eag(ctx->stream, src, H, W, wb, M, tail, d_out, &ctx->tl));
     } else if (quality == PYSP_QUALITY_DRAFT) {

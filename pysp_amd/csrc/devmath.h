@@ -109,6 +109,37 @@ DEVI void rgb2lab_px(LabTab t, float R, float G, float B, float& L, float& a, fl
     b = 200.0f * (fy - fz);
 }
 
+// ---- the other restatement of the same call: OpenCV 4.10's default float32 RGB2Lab (LUT + fixed-point trilinear) ------------
+// Bit-identical to oracle rgb2lab_px_cv410 / oracle/cv2_restated.py "cv410_lut" (restated from memory of color_lab.cpp,
+// unpinned like the closed form).  Selected per context (pysp_ctx_set_lab_mode); tests/lab_flip_rate.py says what it changes.
+//   c = cvRound(clip(v) * 2^14) per channel; cell t = c >> 9 (0..32), position f = (c >> 5) & 15;
+//   33^3 int16 grid of (L, a, b) scaled to 14 bits; weights = products of three factors out of {16 - f, f};
+//   acc = sum over the 8 corners, (acc + 2^11) >> 12;  L = acc * 100/2^14, a = acc * 256/2^14 - 128, b likewise.
+// Device layout of the grid (api.cpp::host_cv410_device_lut): [34][34][34] entries of 16 bytes
+//   { L(x), L(x+1), a(x), a(x+1), b(x), b(x+1), 0, 0 }  (int16; indices clamped to 32, where the matching weight is 0),
+// so one 16-byte load brings both x-corners of a (y, z) corner pair of all three channels, and v_dot2_i32_i16 applies the pair
+// of weights in one instruction: 4 loads (L2-resident, 629 KB) and 12 dot products per pixel.
+constexpr int CV410_DIM = 34;
+DEVI int dot2_i16(unsigned v, int w, int acc) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, v), __builtin_bit_cast(s2, w), acc, false);
+}
+DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B, float& L, float& a, float& b) {
+    const int cx = (int)__builtin_rintf(clip01_cv(R) * 16384.0f), cy = (int)__builtin_rintf(clip01_cv(G) * 16384.0f), cz = (int)__builtin_rintf(clip01_cv(B) * 16384.0f);
+    const int fx = (cx >> 5) & 15, fy = (cy >> 5) & 15, fz = (cz >> 5) & 15;
+    const uint4* e = lut + (((cz >> 9) * CV410_DIM + (cy >> 9)) * CV410_DIM + (cx >> 9));
+    const uint4 v00 = e[0], v10 = e[CV410_DIM], v01 = e[CV410_DIM * CV410_DIM], v11 = e[CV410_DIM * CV410_DIM + CV410_DIM];   // (dy, dz)
+    const int wx = (16 - fx) | (fx << 16);                                   // both x weights in one register; times <= 256 stays inside each half
+    const int w00 = wx * ((16 - fy) * (16 - fz)), w10 = wx * (fy * (16 - fz)), w01 = wx * ((16 - fy) * fz), w11 = wx * (fy * fz);
+    int aL = dot2_i16(v11.x, w11, dot2_i16(v01.x, w01, dot2_i16(v10.x, w10, dot2_i16(v00.x, w00, 0))));
+    int aa = dot2_i16(v11.y, w11, dot2_i16(v01.y, w01, dot2_i16(v10.y, w10, dot2_i16(v00.y, w00, 0))));
+    int ab = dot2_i16(v11.z, w11, dot2_i16(v01.z, w01, dot2_i16(v10.z, w10, dot2_i16(v00.z, w00, 0))));
+    aL = (aL + (1 << 11)) >> 12; aa = (aa + (1 << 11)) >> 12; ab = (ab + (1 << 11)) >> 12;
+    L = (float)aL * (100.0f / 16384.0f);
+    a = (float)aa * (256.0f / 16384.0f) - 128.0f;
+    b = (float)ab * (256.0f / 16384.0f) - 128.0f;
+}
+
 // ---- sRGB transfer curves, transform.py:89-111 -------------------------------------------------
 // x ** (1/2.4) in the reference is a float32 power with the float32 exponent 0.41666666; the oracle
 // returns the correctly rounded value of that power, and so does this routine, without a float64 pow:

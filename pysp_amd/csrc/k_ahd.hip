@@ -43,17 +43,18 @@ constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // 
 enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
 
 // ahd.py:32-62: second white balance, CCM without clip, (HDR: luma + x/(1+x)), Lab
-DEVI void homog_lab(LabTab lt, float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, float& A, float& Bq) {
+// LAB: which restatement of cv2.cvtColor stands in (0 closed form from the LDS tables, 1 OpenCV 4.10's LUT + trilinear path from `lut`)
+template <int LAB>
+DEVI void homog_lab(LabTab lt, const uint4* lut, float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, float& A, float& Bq) {
     float rr = r * wb[0], gg = g * wb[1], bb = b * wb[2];
     float sr = ccm_row(M, rr, gg, bb), sg = ccm_row(M + 3, rr, gg, bb), sb = ccm_row(M + 6, rr, gg, bb);
+    float luma = 0.0f;
     if (hdr) {
-        float luma = 0.2126f * sr + 0.7152f * sg + 0.0722f * sb;
+        luma = 0.2126f * sr + 0.7152f * sg + 0.0722f * sb;
         sr = sr / (1.0f + sr); sg = sg / (1.0f + sg); sb = sb / (1.0f + sb);
-        rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
-        L = luma;
-    } else {
-        rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
     }
+    if (LAB == 1) rgb2lab_cv410(lut, sr, sg, sb, L, A, Bq); else rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
+    if (hdr) L = luma;
 }
 
 // 4x4 window of one Lab plane around a quad: rows/cols -1..2 relative to the quad's top-left pixel.
@@ -147,6 +148,7 @@ struct AhdParams {
     MosaicSrc src;
     float* out;          // (H,W,3)
     const float4* labtab; // LAB_SLOTS entries (lab_tables.h), copied to LDS by every workgroup
+    const uint4* lablut;  // Lab mode 1: the OpenCV-4.10 grid in the device layout of devmath.h (global memory, L2 resident)
     int H, W;
     float wb[3];
     int hdr;
@@ -157,7 +159,7 @@ struct AhdParams {
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
 // HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs
 // registers: 100 VGPRs (4 waves per SIMD) with it compiled in, 92 (5 waves) without -- the non-HDR kernel stays at 92.
-template <bool TINY, bool U16, bool HDR>
+template <bool TINY, bool U16, bool HDR, int LAB>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
     // LDS, 30.6 KB per workgroup (five workgroups per CU).  The mosaic planes are dead once P1 and the green reads below are
     // done, and the horizontal g/D planes once the horizontal P2 is: the Lab buffer of both directions lies over them (a barrier
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                homog_lab(lt, rr[k], gg[k], bb[k], p.wb, M, HDR, labq[k][0], labq[k][1], labq[k][2]);
+                homog_lab<LAB>(lt, p.lablut, rr[k], gg[k], bb[k], p.wb, M, HDR, labq[k][0], labq[k][1], labq[k][2]);
                 rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
 #ifndef AHD_NO_SB
                 __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
@@ -606,9 +608,10 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
 
 // ------------------------------------------------------------------------------------------------
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
-               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, Timeline* tl) {
+               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl) {
     AhdParams a;
     a.labtab = reinterpret_cast<const float4*>(d_labtab);
+    a.lablut = reinterpret_cast<const uint4*>(d_lablut);
     a.src = src; a.H = H; a.W = W; a.hdr = hdr;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
     for (int i = 0; i < 9; i++) a.ccm.m[i] = M[i];
@@ -620,14 +623,15 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
     dim3 ga((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_ahd_select");
     const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
-#define AHD_LAUNCH(HDRV) \
+#define AHD_LAUNCH(HDRV, LABV) \
     do { \
-        if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true, HDRV>), ga, dim3(NT_A), 0, st, a); \
-        else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false, HDRV>), ga, dim3(NT_A), 0, st, a); \
-        else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true, HDRV>), ga, dim3(NT_A), 0, st, a); \
-        else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV>), ga, dim3(NT_A), 0, st, a); \
+        if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
+        else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
+        else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
+        else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
     } while (0)
-    if (hdr) AHD_LAUNCH(true); else AHD_LAUNCH(false);
+    if (d_lablut) { if (hdr) AHD_LAUNCH(true, 1); else AHD_LAUNCH(false, 1); }
+    else { if (hdr) AHD_LAUNCH(true, 0); else AHD_LAUNCH(false, 0); }
 #undef AHD_LAUNCH
     if (tl) tl->end(st);
     const float* cur = a.out;

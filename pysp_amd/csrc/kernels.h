@@ -36,7 +36,8 @@ int launch_colour_tail(hipStream_t st, const float* in, size_t npx, const double
 // k_ahd.hip: tail = colour tail of devmath.h (0 none, 1 lin sRGB, 2 sRGB, 3 Reinhard + sRGB);
 // d_tmp0/d_tmp1 are (H,W,3) scratch images (only needed when stages >= 1 / >= 2).
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
-               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, Timeline* tl = nullptr);
+               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut /* Lab mode 1, else NULL */,
+               Timeline* tl = nullptr);
 
 // k_eag.hip
 int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);

@@ -236,9 +236,9 @@ def main():
             cfa[f"ahd1_{pat.name}"] = np.ascontiguousarray(rb.demosaic(QualityDemosaic.Best, 1).image)
         save("g8_cfa_patterns", {"ref": "image.py:143-152,181,185-197", "cv2_restated": True, "colour_shim": True, "io_stubs": True}, **cfa)
 
-        # The same AHD frames with the OTHER Lab restatement standing in for cv2.cvtColor (OpenCV 4.10's LUT + trilinear
-        # float path, oracle/cv2_restated.py LAB_MODE "cv410_lut"): pins the oracle's lab mode 1 and whatever follows it.
-        cv2_restated.LAB_MODE = "cv410_lut"
+        # The same AHD frames with the OTHER Lab restatement standing in for cv2.cvtColor (the closed form of round 1,
+        # oracle/cv2_restated.py LAB_MODE "closed_form"): pins lab mode 0 of the oracle and of the product.
+        cv2_restated.LAB_MODE = "closed_form"
         try:
             for (H, W), hdr in (((32, 48), False), ((34, 50), True)):
                 bay = scene(H, W, 1000 + H, scale=3.0 if hdr else 1.0)
@@ -250,10 +250,10 @@ def main():
                     im = RawRggbBayerData(bay, FakeWb(MULT, mat), 10.0, 1.0)
                     im.set_hdr(hdr)
                     out[f"ahd{st}"] = im.demosaic(QualityDemosaic.Best, st).image
-                save(f"g8_labmode_cv410lut_{H}x{W}{'_hdr' if hdr else ''}",
-                     {"ref": "debayer/ahd.py:32-67", "cv2_restated": True, "lab_mode": "cv410_lut", "colour_shim": True, "io_stubs": True, "hdr": hdr}, **out)
+                save(f"g8_labmode_closed_form_{H}x{W}{'_hdr' if hdr else ''}",
+                     {"ref": "debayer/ahd.py:32-67", "cv2_restated": True, "lab_mode": "closed_form", "colour_shim": True, "io_stubs": True, "hdr": hdr}, **out)
         finally:
-            cv2_restated.LAB_MODE = "closed_form"
+            cv2_restated.LAB_MODE = "cv410_lut"
 
         # resample_channel / resample_g standalone
         sub = rng.random((9, 7), dtype=np.float32); gs = rng.random((9, 7), dtype=np.float32); hf = (rng.random((18, 14), dtype=np.float32) - 0.5)

@@ -3,8 +3,8 @@
 
 cv2.cvtColor(COLOR_RGB2LAB) (debayer/ahd.py:58,62 of the reference) is third-party arithmetic that cannot be pinned in this
 image (no cv2).  Two restatements exist (oracle/cv2_restated.py, oracle/pysp_oracle.c):
-    mode 0  closed form, table-driven pow / cbrt            -- what the product kernels compute
-    mode 1  OpenCV 4.10's LUT (33^3, 14 bit) + trilinear path -- what the reference most likely runs
+    mode 0  closed form, table-driven pow / cbrt              -- round 1's metric, still selectable (pysp_ctx_set_lab_mode)
+    mode 1  OpenCV 4.10's LUT (33^3, 14 bit) + trilinear path -- what the reference most likely runs; the default since round 2
 AHD thresholds on these values with `<=` (debayer/ahd_homogeneity_cython.pyx:56-57), so this script measures, on the benchmark's
 synthetic 24 MP frame and on pure noise: how many homogeneity counts differ, how many H/V decisions flip, and how far the
 demosaiced / sRGB output moves.  Numbers quoted in DESIGN.md section 3.
@@ -46,7 +46,7 @@ def main():
                                  cand_differ=(t["r_h"] != t["r_v"]) | (t["g_h"] != t["g_v"]) | (t["b_h"] != t["b_v"]),
                                  srgb=oracle.pipeline_srgb(bay, wb, M, 2, args.hdr, 1, args.hdr))
             finally:
-                oracle.set_lab_mode(0)
+                oracle.set_lab_mode(oracle.DEFAULT_LAB_MODE)
         a, b = res[0], res[1]
         flips = a["take_h"] != b["take_h"]
         d0 = np.abs(a["out0"] - b["out0"])

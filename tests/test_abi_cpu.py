@@ -196,7 +196,7 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
     bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     hot = [v for k, v in kernels.items() if "k_ahd_select" in k or "k_ahd_median_stage" in k]
-    assert len(hot) == 9                                             # eight select variants (tiny / uint16 / HDR metric) and the median stage
+    assert len(hot) == 17                                            # sixteen select variants (tiny / uint16 / HDR metric / Lab restatement) and the median stage
     for v in hot:                                                    # five 256-thread workgroups per CU: <= 96 VGPRs and <= 32 KB of LDS each
         assert v["vgpr_count"] <= 96 and v["group_segment_fixed_size"] <= 32768, v
 
@@ -224,3 +224,14 @@ def test_bench_bare_multi_gpu_invocation_becomes_a_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--workload", "cfg3", "--steps", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert had_torch or "torch" not in sys.modules            # the parent did not even import torch
+
+
+def test_cv410_lab_grid_equals_the_oracles_and_numpys(orc):
+    """Lab mode 1 (OpenCV 4.10 LUT + trilinear): the product builds its own 33^3 grid on the host (api.cpp::host_cv410_lut); it must
+    equal the C oracle's and the NumPy restatement's bit for bit -- three independent builds of one definition."""
+    import ctypes
+    from oracle import cv2_restated
+    from pysp_amd import _lib
+    out = np.empty((33, 33, 33, 3), np.int16)
+    _lib.check(_lib.lib().pysp_lab_cv410_lut(ctypes.c_void_p(out.ctypes.data)))
+    assert np.array_equal(out, orc.cv410_lut()) and np.array_equal(out, cv2_restated.cv410_lab_lut())

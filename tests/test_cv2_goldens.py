@@ -99,7 +99,7 @@ def test_real_cv2_full_reference_pipeline(orc, name):
         try:
             got = orc.demosaic_ahd(d["bayer"], wb, M, hdr, 0)
         finally:
-            orc.set_lab_mode(0)
+            orc.set_lab_mode(orc.DEFAULT_LAB_MODE)
         rates[mode] = float(np.mean(ulp_diff(got, d["ahd0"]).max(axis=-1) > 4))      # pixels that took the other direction
     print(name, "fraction of pixels whose H/V decision differs from the real-cv2 reference, per Lab mode:", rates)
     assert min(rates.values()) <= 0.01, rates

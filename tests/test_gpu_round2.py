@@ -371,3 +371,44 @@ def test_host_pipeline_in_overlapped_bands_equals_whole_frame(orc, wbobj):
     _lib.check(L.pysp_pipeline_u16_f32(ctx.handle, _lib.ptr(raw), H, W, black, sat, _lib.wb3(wb), _lib.mat9(M), 2, 0, 1, 2, _lib.ptr(out)))
     want = pipe.raw_u16_to_rgb(torch.from_numpy(raw.view(np.int16)).cuda(), list(black), list(sat), wb, M, _lib.QUALITY_BEST, 1, 2).cpu().numpy()
     assert np.array_equal(out, want)
+
+
+# ---- Lab modes: 1 (default) = the OpenCV-4.10 LUT + trilinear restatement, 0 = the closed form of round 1 ----------------
+def test_lab_modes(orc, wbobj):
+    """Every other test runs in the default mode 1 (fixtures g8_demosaic_* come from the reference's unchanged ahd.py with the
+    NumPy cv410_lut restatement as cv2.cvtColor).  Here: pysp_ctx_set_lab_mode(ctx, 0) against the closed-form fixtures and the
+    oracle in mode 0 -- larger frames, the HDR metric, non-finite sites -- and the size of the difference between the modes."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    ctx = _lib.default_context()
+    pipe = DevicePipeline(0)
+    assert ctx.get_lab_mode() == 1 and pipe.ctx.get_lab_mode() == 1 and orc.DEFAULT_LAB_MODE == 1
+    big = rggb_frame(1000, 1504, 1000)
+    a = pipe.demosaic(torch.from_numpy(big).cuda(), wb, M, _lib.QUALITY_BEST, False, 0).cpu().numpy()
+    assert np.array_equal(a, orc.demosaic_ahd(big, wb, M, False, 0))
+    try:
+        ctx.set_lab_mode("closed_form"); pipe.ctx.set_lab_mode(0); orc.set_lab_mode(0)
+        for name in ("g8_labmode_closed_form_32x48", "g8_labmode_closed_form_34x50_hdr"):
+            d, meta = load_golden(name)
+            for st in (0, 1):
+                im = RawRggbBayerData(d["bayer"], wbobj, 10.0, 1.0)
+                im.set_hdr(meta["hdr"])
+                assert np.array_equal(im.demosaic(QualityDemosaic.Best, st).image, d[f"ahd{st}"]), (name, st)
+        for (H, W, hdr, stages) in ((130, 158, False, 0), (256, 384, False, 1), (200, 264, True, 1), (66, 130, True, 0), (2, 2, False, 0), (6, 4, True, 1)):
+            bay = rggb_frame(H, W, 500 + H, scale=3.0 if hdr else 1.0, clip_hi=not hdr)
+            got = pipe.demosaic(torch.from_numpy(bay).cuda(), wb, M, _lib.QUALITY_BEST, hdr, stages).cpu().numpy()
+            assert np.array_equal(got, orc.demosaic_ahd(bay, wb, M, hdr, stages)), (H, W, hdr, stages)
+        bay = _poisoned(96, 128, 8)
+        got = pipe.demosaic(torch.from_numpy(bay).cuda(), wb, M, _lib.QUALITY_BEST, False, 0).cpu().numpy()
+        assert _same(got, orc.demosaic_ahd(bay, wb, M, False, 0))
+        b = pipe.demosaic(torch.from_numpy(big).cuda(), wb, M, _lib.QUALITY_BEST, False, 0).cpu().numpy()
+        assert np.array_equal(b, orc.demosaic_ahd(big, wb, M, False, 0))
+    finally:
+        ctx.set_lab_mode(1); pipe.ctx.set_lab_mode(1); orc.set_lab_mode(orc.DEFAULT_LAB_MODE)
+    flips = np.mean((a != b).any(axis=-1))
+    assert 0.005 < flips < 0.08, flips                 # the two restatements disagree on a few percent of the H/V decisions (DESIGN.md section 3)

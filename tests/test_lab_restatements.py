@@ -53,7 +53,12 @@ def test_fmaf_emulation_is_exactly_rounded(cv):
 
 def test_closed_form_numpy_equals_c_oracle_bit_for_bit(orc, cv):
     x = _probe()
-    assert np.array_equal(cv.cvtColor(x, cv.COLOR_RGB2LAB, mode="closed_form"), orc.rgb2lab(x))
+    try:
+        orc.set_lab_mode(0)
+        got = orc.rgb2lab(x)
+    finally:
+        orc.set_lab_mode(orc.DEFAULT_LAB_MODE)
+    assert np.array_equal(cv.cvtColor(x, cv.COLOR_RGB2LAB, mode="closed_form"), got)
     dec, cb = cv.lab_tables()                        # NumPy builds the tables from libm itself
     od, oc = orc.lab_tables()
     assert np.array_equal(dec, od) and np.array_equal(cb, oc)
@@ -61,12 +66,8 @@ def test_closed_form_numpy_equals_c_oracle_bit_for_bit(orc, cv):
 
 def test_cv410_lut_numpy_equals_c_oracle_bit_for_bit(orc, cv):
     x = _probe(6)
-    try:
-        orc.set_lab_mode(1)
-        got = orc.rgb2lab(x)
-    finally:
-        orc.set_lab_mode(0)
-    assert np.array_equal(cv.cvtColor(x, cv.COLOR_RGB2LAB, mode="cv410_lut"), got)
+    assert orc.DEFAULT_LAB_MODE == 1 and cv.LAB_MODE == "cv410_lut"          # the default everywhere
+    assert np.array_equal(cv.cvtColor(x, cv.COLOR_RGB2LAB, mode="cv410_lut"), orc.rgb2lab(x))
     assert np.array_equal(cv.cv410_lab_lut(), orc.cv410_lut())
 
 
@@ -91,18 +92,19 @@ def test_cv410_lut_structure(cv):
     assert d[:, 0].max() < 0.5 and d[:, 1:].max() < 1.5          # interpolation error of the 33^3 grid, largest near black
 
 
-@pytest.mark.parametrize("name", ["g8_labmode_cv410lut_32x48", "g8_labmode_cv410lut_34x50_hdr"])
-def test_oracle_lab_mode_1_reproduces_reference_orchestration(orc, name):
-    """The reference's unchanged ahd.py with the cv410_lut NumPy restatement as cv2.cvtColor == C oracle in lab mode 1."""
+@pytest.mark.parametrize("name", ["g8_labmode_closed_form_32x48", "g8_labmode_closed_form_34x50_hdr"])
+def test_oracle_lab_mode_0_reproduces_reference_orchestration(orc, name):
+    """The reference's unchanged ahd.py with the closed-form NumPy restatement as cv2.cvtColor == C oracle in lab mode 0
+    (the default mode, 1, is what every g8_demosaic_* fixture pins)."""
     d, meta = load_golden(name)
     wb = (1.0 / d["mult"]).astype(np.float32)
     M = orc.final_matrix(d["xyz2cam"], d["white_xyz"])
     try:
-        orc.set_lab_mode(1)
+        orc.set_lab_mode(0)
         for st in (0, 1):
             assert np.array_equal(orc.demosaic_ahd(d["bayer"], wb, M, meta["hdr"], st), d[f"ahd{st}"]), st
     finally:
-        orc.set_lab_mode(0)
+        orc.set_lab_mode(orc.DEFAULT_LAB_MODE)
 
 
 def test_g8_cfa_patterns_all_qualities(orc):

@@ -73,9 +73,17 @@ def test_lab_pow_cbrt_accuracy(orc):
 
 
 def test_rgb2lab_against_closed_form(orc):
+    """Lab mode 0 (closed form with table-driven pow / cbrt) against plain float64 CIELab; mode 1 (the default, OpenCV 4.10's
+    33^3 LUT + trilinear) is by construction only an interpolation of it: within 0.5 in L and 1.5 in a, b."""
     rng = np.random.default_rng(9)
     rgb = (rng.random((64, 64, 3)) * 1.4 - 0.2).astype(np.float32)
-    lab = orc.rgb2lab(rgb).astype(np.float64)
+    lut = orc.rgb2lab(rgb).astype(np.float64)
+    try:
+        orc.set_lab_mode(0)
+        lab = orc.rgb2lab(rgb).astype(np.float64)
+        white = orc.rgb2lab(np.ones((1, 1, 3), np.float32))
+    finally:
+        orc.set_lab_mode(orc.DEFAULT_LAB_MODE)
     c = np.clip(rgb.astype(np.float64), 0, 1)
     lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
     m = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
@@ -84,7 +92,7 @@ def test_rgb2lab_against_closed_form(orc):
     L = np.where(xyz[..., 1] > 0.008856, 116 * f[..., 1] - 16, 903.3 * xyz[..., 1])
     ref = np.stack([L, 500 * (f[..., 0] - f[..., 1]), 200 * (f[..., 1] - f[..., 2])], axis=-1)
     assert np.max(np.abs(lab - ref)) < 5e-4
-    white = orc.rgb2lab(np.ones((1, 1, 3), np.float32))
+    assert np.max(np.abs(lut - ref)[..., 0]) < 0.5 and np.max(np.abs(lut - ref)[..., 1:]) < 1.5
     assert abs(white[0, 0, 0] - 100) < 1e-3 and np.max(np.abs(white[0, 0, 1:])) < 2e-2
 
 

@@ -20,7 +20,7 @@ for g in "${groups[@]}"; do
   out=$root/gpurun_out/pmc_$tag/g$i
   mkdir -p "$out"
   (cd /tmp && rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$out" -o p -- \
-      python3 "$root/bench.py" --steps 8 --warmup 1 --streams 1 --no-cpu-baseline "$@" > "$out/bench.log" 2>&1)
+      python3 "$root/bench.py" --steps 8 --warmup 1 --streams 1 --settle 0 --no-cpu-baseline "$@" > "$out/bench.log" 2>&1)
   echo "pass $i done: $g"
   i=$((i+1))
 done
