@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     float* const lab = planes;                       // [3][LPR][LPS], one direction at a time
     float* const gq0 = planes + 4 * MWY * MWX;       // horizontal: GHR, GHB, DHR, DHB
     float* const gq1 = planes + NFRONT;              // vertical:   GVR, GVB, DVR, DVB
-    __shared__ float4 s_labtab[LAB_SLOTS];                                  // 12 KB
+    __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 128];                 // 12 KB of closed-form tables; Lab mode 1 reads its grid from L2 and keeps only the vote map here
     unsigned short* const vmap = reinterpret_cast<unsigned short*>(s_labtab);   // [MPR][MPS] votes: h | v << 8
     static_assert(MPR * MPS * sizeof(unsigned short) <= (((127 + LAB_DEC_LOEXP) << LAB_DEC_NB) & (LAB_DEC_SLOTS - 1)) * sizeof(float4),
                   "the vote map must end before the first used slot of the decode table");
@@ -192,9 +192,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     {
         constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT_A - 1) / NT_A;
         static_assert(LAB_SLOTS % NT_A == 0, "table copy assumes whole rounds");
-        constexpr int NTAB = LAB_SLOTS / NT_A;
+        constexpr int NTAB = LAB == 0 ? LAB_SLOTS / NT_A : 0;
         float2 tmp[NL];
-        float4 ttab[NTAB];
+        float4 ttab[NTAB + 1];
 #pragma unroll
         for (int k = 0; k < NTAB; k++) ttab[k] = p.labtab[tid + k * NT_A];
 #pragma unroll
