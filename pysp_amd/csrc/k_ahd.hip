@@ -369,19 +369,19 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         }
         if (at_top) { s012[0] = s012[2]; s123[0] = s123[2]; }                     // row -1 -> row 1
         if (at_bot) { s012[3] = s012[1]; s123[3] = s123[1]; }                     // row H -> row H-2
+        float px[4][3];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int dy = k >> 1, dx = k & 1;
             unsigned int s = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
             unsigned int sh = s & 0xFFu, sv = s >> 8;
             float c = sh < sv ? 1.0f : 0.0f, nc = 1.0f - c;            // ahd.py:139-145, literally
-            float r = rgbh[k][0] * c + rgbv[k][0] * nc;
-            float g = rgbh[k][1] * c + rgbv[k][1] * nc;
-            float b = rgbh[k][2] * c + rgbv[k][2] * nc;
-            colour_tail(p.tail, M, r, g, b);
-            float* o = p.out + ((size_t)(2 * qi + dy) * W + (2 * qj + dx)) * 3;
-            o[0] = r; o[1] = g; o[2] = b;
+            px[k][0] = rgbh[k][0] * c + rgbv[k][0] * nc;
+            px[k][1] = rgbh[k][1] * c + rgbv[k][1] * nc;
+            px[k][2] = rgbh[k][2] * c + rgbv[k][2] * nc;
+            colour_tail(p.tail, M, px[k][0], px[k][1], px[k][2]);
         }
+        store_quad_direct(p.out, W, qi, qj, px);                       // two rows of three 8-byte stores instead of twelve dword stores
     }
 }
 
@@ -473,8 +473,10 @@ DEVI void load_run4_window(const float* plane, int stride, int ly, int lx, float
 }
 
 #ifndef MED_MIN_WAVES
-#define MED_MIN_WAVES 1                            // 104 VGPRs, 4 waves/SIMD.  Forcing 5 (96 VGPRs, 5 spilled to scratch) measured 2 % faster,
-                                                  // but the two-process band test then failed: no kernel of this library uses scratch
+#define MED_MIN_WAVES 1                            // round 1: 104 VGPRs; forcing 5 waves (96 VGPRs, 5 spilled to scratch) measured 2 % faster, but the two-process
+                                                  // band test then failed: no kernel of this library uses scratch.  Round 2: 65 VGPRs, LDS-limited to five workgroups per
+                                                  // CU.  Measured and dropped: g-b' laid over the dead r-g plane (two first-level passes, one more barrier): 24.4 KB,
+                                                  // six workgroups per CU, 72 VGPRs -- 0.339 -> 0.343 ms: the stage is bound by instruction issue, not by latency
 #endif
 __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedParams p) {
     __shared__ __attribute__((aligned(16))) float s_g[B4Y][B4X], s_drg[B4Y][B4X], s_dbg[B4Y][B4X];   // g, r-g, b-g (halo 4)
@@ -596,12 +598,25 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
 #pragma unroll
         for (int q = 0; q < 4; q++) gq[q] = (((ma[q] + mb[q]) + keep_r[k][q]) + keep_b[k][q]) / 2.0f;
         float* dst = p.out + ((size_t)y * W + x) * 3;
+        if (!(W & 3)) {
+            // W % 4 == 0: the run's 48 bytes are 16-byte aligned and wholly inside the image -> three 16-byte stores, each issued as soon
+            // as its floats exist (pixel by pixel: the float64 tails of four pixels do not pile up in registers)
+            float o[12];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (q >= 2 && x + 2 >= W) break;         // the second pair only if it is inside the image
-            float r = keep_r[k][q], g = gq[q], b = keep_b[k][q];
-            colour_tail(p.tail, p.ccm.m, r, g, b);
-            dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b;   // one pixel at a time: the float64 tails of four pixels do not pile up in registers
+            for (int q = 0; q < 4; q++) {
+                float r = keep_r[k][q], g = gq[q], b = keep_b[k][q];
+                colour_tail(p.tail, p.ccm.m, r, g, b);
+                o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
+                if (q >= 1) reinterpret_cast<float4*>(dst)[q - 1] = make_float4(o[4 * q - 4], o[4 * q - 3], o[4 * q - 2], o[4 * q - 1]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q >= 2 && x + 2 >= W) break;         // the second pair only if it is inside the image
+                float r = keep_r[k][q], g = gq[q], b = keep_b[k][q];
+                colour_tail(p.tail, p.ccm.m, r, g, b);
+                dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b;
+            }
         }
     }
 }
