@@ -1,0 +1,38 @@
+#!/bin/bash
+# One GPU-box call that produces every measurement artefact of a round (copied into profiles/ afterwards):
+#   bash tools/collect_profiles.sh r2      (through gpurun; results under gpurun_out/<tag>_final/)
+# rocprofv3 runs the program itself (python3 bench.py ...), never a shell or env wrapper; --pmc passes are separate from the stats pass.
+set -o pipefail
+tag=${1:-r2}
+root=$(pwd)
+out=$root/gpurun_out/${tag}_final
+mkdir -p "$out"
+export TMPDIR=/tmp
+one() { python3 "$root/bench.py" "$@" 2>>"$out/bench.err" | grep '^{' ; }
+# 1. the driver's own command shape, then the default run
+one --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_20_5.json"
+one > "$out/bench.json"
+echo "bench done"
+# 2. kernel trace + stats of the default command
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o s -- python3 "$root/bench.py" --no-cpu-baseline > "$out/stats.log" 2>&1)
+find "$out/stats" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
+echo "stats done"
+# 3. every other workload (one JSON line each)
+: > "$out/workloads.jsonl"
+for w in ahd24u16 eag24 eag24ccm eag24raw draft12 fuse45 warp100 cfg3 cfg5; do one --workload $w --no-cpu-baseline >> "$out/workloads.jsonl"; done
+one --lab-mode closed_form --no-cpu-baseline >> "$out/workloads.jsonl"
+one --gpus 2 --backend gloo --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline >> "$out/workloads.jsonl"
+one --gpus 2 --backend gloo --workload cfg3 --steps 20 --warmup 3 --no-cpu-baseline >> "$out/workloads.jsonl"
+echo "workloads done"
+# 4. hardware counters of the default workload and of the EAG / Draft / warp kernels
+bash "$root/tools/pmc_collect.sh" ${tag}_ahd24 > "$out/pmc_ahd24.log" 2>&1
+bash "$root/tools/pmc_collect.sh" ${tag}_eag24ccm --workload eag24ccm > "$out/pmc_eag.log" 2>&1
+bash "$root/tools/pmc_collect.sh" ${tag}_draft12 --workload draft12 > "$out/pmc_draft.log" 2>&1
+bash "$root/tools/pmc_collect.sh" ${tag}_warp100 --workload warp100 > "$out/pmc_warp.log" 2>&1
+for k in ahd24 eag24ccm draft12 warp100; do cp "$root/gpurun_out/pmc_${tag}_${k}_summary.csv" "$out/pmc_${k}_summary.csv"; done
+echo "pmc done"
+# 5. PCIe-inclusive timings of the drop-in API, whole configs 4 / 5 on one GPU
+python3 "$root/tools/dropin_time.py" > "$out/dropin_time.log" 2>&1
+python3 "$root/tools/config_time.py" > "$out/config_time.log" 2>&1
+python3 "$root/tests/ref_native_time.py" gpu > "$out/native_units_gpu.log" 2>&1
+echo "all done"
