@@ -66,7 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="ahd24", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=3, help="distinct resident input frames per rank, cycled (cfg3: frames per rank per step, default 8)")
+    ap.add_argument("--frames", type=int, default=8, help="distinct resident input frames per rank, cycled: one batch, i.e. one parameter broadcast per --frames steps at N > 1 (cfg3: frames per rank per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (contexts) the frames of a rank are cycled over.  With 2, consecutive (independent) frames overlap: the next "
@@ -170,7 +170,7 @@ def main() -> None:
         from pysp_amd.pipeline import DevicePipeline
         pipe = DevicePipeline(dev_index)
         kernel_ctx = pipe.ctx
-        nf = args.frames if args.frames != 3 else 8
+        nf = args.frames
         frames_per_step = nf
         frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * nf + i)).to(dev) for i in range(nf)]      # frame i of rank r: seed 1000 + r*nf + i
         outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(nf)]
