@@ -62,7 +62,7 @@ struct pysp_ctx {
     float* lanczos = nullptr;
     float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
     int lab_mode = 1;            // 1 (default): OpenCV 4.10's LUT + trilinear restatement; 0: closed-form Lab (tables above)
-    void* lablut = nullptr;      // mode 1: [34][34][34] x 32 B grid (devmath.h)
+    void* lablut = nullptr;      // mode 1: [34][34][34] x 64 B grid (devmath.h)
     Timeline tl;
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
     hipStream_t copy_stream = nullptr;
@@ -172,14 +172,18 @@ static void host_cv410_device_lut(std::vector<int16_t>& dev) {
     std::vector<int16_t> lut(33 * 33 * 33 * 3);
     host_cv410_lut(lut.data());
     const int D = 34;
-    dev.assign((size_t)D * D * D * 16, 0);
+    dev.assign((size_t)D * D * D * 32, 0);
     auto at = [&](int z, int y, int x, int c) { z = z > 32 ? 32 : z; y = y > 32 ? 32 : y; x = x > 32 ? 32 : x; return lut[((size_t)(z * 33 + y) * 33 + x) * 3 + c]; };
     for (int z = 0; z < D; z++)
         for (int y = 0; y < D; y++)
             for (int x = 0; x < D; x++) {
-                int16_t* e = &dev[(((size_t)z * D + y) * D + x) * 16];
-                for (int dy = 0; dy < 2; dy++)
-                    for (int c = 0; c < 3; c++) { e[6 * dy + 2 * c] = at(z, y + dy, x, c); e[6 * dy + 2 * c + 1] = at(z, y + dy, x + 1, c); }
+                int16_t* e = &dev[(((size_t)z * D + y) * D + x) * 32];
+                for (int dz = 0; dz < 2; dz++)
+                    for (int dy = 0; dy < 2; dy++)
+                        for (int c = 0; c < 3; c++) {
+                            int16_t* o = e + ((dz * 2 + dy) * 3 + c) * 2;
+                            o[0] = at(z + dz, y + dy, x, c); o[1] = at(z + dz, y + dy, x + 1, c);
+                        }
             }
 }
 

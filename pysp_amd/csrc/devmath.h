@@ -115,12 +115,12 @@ DEVI void rgb2lab_px(LabTab t, float R, float G, float B, float& L, float& a, fl
 //   c = cvRound(clip(v) * 2^14) per channel; cell t = c >> 9 (0..32), position f = (c >> 5) & 15;
 //   33^3 int16 grid of (L, a, b) scaled to 14 bits; weights = products of three factors out of {16 - f, f};
 //   acc = sum over the 8 corners, (acc + 2^11) >> 12;  L = acc * 100/2^14, a = acc * 256/2^14 - 128, b likewise.
-// Device layout of the grid (api.cpp::host_cv410_device_lut): [34][34][34] entries of 32 bytes
-//   { L(x,y), L(x+1,y), a(x,y), a(x+1,y), b(x,y), b(x+1,y), L(x,y+1), L(x+1,y+1), a(x,y+1), a(x+1,y+1), b(x,y+1), b(x+1,y+1), 0 x 4 }
-// (int16; indices clamped to 32, where the matching weight is 0): the four (x, y) corners of one z level are 24 contiguous
-// bytes of ONE cache line (a 16-byte and an 8-byte load), and v_dot2_i32_i16 applies the two x weights in one instruction:
-// two line requests and 12 dot products per pixel on a 1.26 MB L2-resident grid.
-// (Measured: 16-byte entries holding one (y, z) corner pair, four line requests per pixel: select kernel 0.3735 ms; this layout: see DESIGN.md.)
+// Device layout of the grid (api.cpp::host_cv410_device_lut): [34][34][34] entries of 64 bytes = one cache line holding all eight
+// corners of the cell: for (dz, dy) = (0,0), (0,1), (1,0), (1,1) the int16 pairs { L(x), L(x+1) }, { a(x), a(x+1) }, { b(x), b(x+1) }
+// (indices clamped to 32, where the matching weight is 0), 48 bytes + 16 of padding.  v_dot2_i32_i16 applies the two x weights in one
+// instruction: three 16-byte loads from ONE line and 12 dot products per pixel on a 2.5 MB L2-resident grid.  The per-lane gathers are
+// what this mode costs (a timing build with every lane on one line: select kernel 0.368 -> 0.333 ms); measured layouts: 16-byte entries
+// (one (y, z) corner pair each, four lines per pixel) 0.3735 ms, 32-byte entries (one z level each, two lines) 0.366 ms, this one: DESIGN.md.
 constexpr int CV410_DIM = 34;
 DEVI int dot2_i16(unsigned v, int w, int acc) {
     typedef short s2 __attribute__((ext_vector_type(2)));
@@ -129,14 +129,13 @@ DEVI int dot2_i16(unsigned v, int w, int acc) {
 DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B, float& L, float& a, float& b) {
     const int cx = (int)__builtin_rintf(clip01_cv(R) * 16384.0f), cy = (int)__builtin_rintf(clip01_cv(G) * 16384.0f), cz = (int)__builtin_rintf(clip01_cv(B) * 16384.0f);
     const int fx = (cx >> 5) & 15, fy = (cy >> 5) & 15, fz = (cz >> 5) & 15;
-    const uint4* e = lut + 2 * (((cz >> 9) * CV410_DIM + (cy >> 9)) * CV410_DIM + (cx >> 9));
-    const uint4 lo0 = e[0], lo1 = e[2 * CV410_DIM * CV410_DIM];                                              // z, z + 1: (L, a, b)(y), L(y+1)
-    const uint2 hi0 = *reinterpret_cast<const uint2*>(e + 1), hi1 = *reinterpret_cast<const uint2*>(e + 2 * CV410_DIM * CV410_DIM + 1);   // (a, b)(y+1)
+    const uint4* e = lut + 4 * (((cz >> 9) * CV410_DIM + (cy >> 9)) * CV410_DIM + (cx >> 9));
+    const uint4 q0 = e[0], q1 = e[1], q2 = e[2];      // 12 dwords of one 64-byte line: (dz, dy) = (0,0), (0,1), (1,0), (1,1), each (L, a, b) as x pairs
     const int wx = (16 - fx) | (fx << 16);                                   // both x weights in one register; times <= 256 stays inside each half
     const int w00 = wx * ((16 - fy) * (16 - fz)), w10 = wx * (fy * (16 - fz)), w01 = wx * ((16 - fy) * fz), w11 = wx * (fy * fz);   // (dy, dz)
-    int aL = dot2_i16(lo1.w, w11, dot2_i16(lo1.x, w01, dot2_i16(lo0.w, w10, dot2_i16(lo0.x, w00, 0))));
-    int aa = dot2_i16(hi1.x, w11, dot2_i16(lo1.y, w01, dot2_i16(hi0.x, w10, dot2_i16(lo0.y, w00, 0))));
-    int ab = dot2_i16(hi1.y, w11, dot2_i16(lo1.z, w01, dot2_i16(hi0.y, w10, dot2_i16(lo0.z, w00, 0))));
+    int aL = dot2_i16(q2.y, w11, dot2_i16(q1.z, w01, dot2_i16(q0.w, w10, dot2_i16(q0.x, w00, 0))));
+    int aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 0))));
+    int ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 0))));
     aL = (aL + (1 << 11)) >> 12; aa = (aa + (1 << 11)) >> 12; ab = (ab + (1 << 11)) >> 12;
     L = (float)aL * (100.0f / 16384.0f);
     a = (float)aa * (256.0f / 16384.0f) - 128.0f;
