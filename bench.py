@@ -77,6 +77,8 @@ def parse_args(argv=None):
     ap.add_argument("--lab-mode", default="cv410_lut", choices=["closed_form", "cv410_lut"],
                     help="restatement of cv2.cvtColor(RGB2LAB) behind AHD's homogeneity vote (pysp_ctx_set_lab_mode)")
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even at world size 1 (under a launcher): exercises the RCCL broadcast / all_reduce / barrier code path on one GPU")
     ap.add_argument("--settle", type=float, default=0.4,
                     help="seconds of untimed steps run BEFORE the W warmup steps so that the clocks have reached their loaded state when a short "
                          "(e.g. 20-step) timed region starts; 0 disables.  The timed region is exactly K steps either way")
@@ -109,7 +111,7 @@ def main() -> None:
     n_dev = max(1, torch.cuda.device_count())
     dev_index = local_rank % n_dev                 # one rank per GPU; the modulo only matters for a gloo rehearsal on fewer GPUs
     torch.cuda.set_device(dev_index)
-    if world_env > 1:
+    if world_env > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -256,6 +256,25 @@ def test_bench_cfg3_batch_two_ranks_and_single():
     assert one["n_gpus"] == 1 and one["config"]["frames_per_step_total"] == 2 and one["value"] > 0
 
 
+def test_bench_rccl_code_path_on_one_gpu():
+    """The N > 1 code path with the real backend ("nccl" = RCCL): process group on the GPU, parameter broadcast inside the timed region,
+    all_reduce of the elapsed time, barriers -- at world size 1 under the launcher the driver uses, because the box has one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for wl in ("ahd24", "cfg3", "cfg5"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29571",
+               os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--workload", wl, "--steps", "4", "--warmup", "1", "--frames", "2", "--no-cpu-baseline", "--settle", "0"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert out.returncode == 0 and len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 1 and line["config"]["backend"] == "rccl" and line["value"] > 0, line
+
+
 def test_bench_default_line_contract():
     """The driver's own command shape (N = 1, short run): metric, config, roofline with the VALU bound, cpu_baseline."""
     line = _bench("--gpus", "1", "--steps", "20", "--warmup", "5")
