@@ -48,6 +48,8 @@ WORKLOADS = {
     "ahd24u16": (4000, 6000, 2, 1, "24MP RGGB uint16 sensor mosaic, bayer_normalize fused into the tile loader + AHD (postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb (14 B/px)"),
     "eag24": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + to_lin_srgb + lin_srgb_to_srgb"),
     "draft12": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + to_lin_srgb + lin_srgb_to_srgb"),
+    "draft12ccm": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + WB + 3x3 CCM (to_lin_srgb)", 1),
+    "draft12raw": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft only (RawDemosaicData.image)", 0),
     "eag24ccm": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + WB + 3x3 CCM (to_lin_srgb), BASELINE config 3 per frame", 1),
     "eag24raw": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) only (RawDemosaicData.image)", 0),
     # secondary kernels (BASELINE configs 4 and 5), reported with their own algorithmic bytes
