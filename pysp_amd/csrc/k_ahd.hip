@@ -406,9 +406,23 @@ constexpr int NT_B = MED_NT;
 // count of these ops is what bounds the kernel).  Exhaustive 0-1 check: tools/check_median25.c.
 // The kernel always handles a horizontally adjacent pixel pair: the two 5x5 windows share 20 elements, the
 // 13 exchanges that involve only those are evaluated once (-17 % ops), the rest runs on both in lockstep.
-#define CE1(v, a, b) { float _t = fminf(v[a], v[b]); v[b] = fmaxf(v[a], v[b]); v[a] = _t; }
-#define S31(v, a, b, c) { float _lo = fminf(fminf(v[a], v[b]), v[c]); float _hi = fmaxf(fmaxf(v[a], v[b]), v[c]); \
-                          float _md = __builtin_amdgcn_fmed3f(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
+// The networks are spelled with raw VALU instructions: fminf / fmaxf are llvm.minnum / maxnum, for which the backend (IEEE mode) first
+// canonicalises every operand it cannot prove quiet -- one extra v_max_f32 x, x per value loaded from LDS, 76 of the stage's 2 478
+// vector instructions.  A signalling NaN is the only input the two forms treat differently, and those are outside the contract
+// (DESIGN.md section 6).  Plain (non-volatile) asm with register operands: the compiler schedules and allocates around it as usual.
+DEVI float vmin2(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+DEVI float vmax2(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+DEVI float vmin3(float a, float b, float c) { float d; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+DEVI float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+DEVI float vmed3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+#define MN2(a, b) vmin2(a, b)
+#define MX2(a, b) vmax2(a, b)
+#define MN3(a, b, c) vmin3(a, b, c)
+#define MX3(a, b, c) vmax3(a, b, c)
+#define MD3(a, b, c) vmed3(a, b, c)
+#define CE1(v, a, b) { float _t = MN2(v[a], v[b]); v[b] = MX2(v[a], v[b]); v[a] = _t; }
+#define S31(v, a, b, c) { float _lo = MN3(v[a], v[b], v[c]); float _hi = MX3(v[a], v[b], v[c]); \
+                          float _md = MD3(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
 // w: 5 rows x 6 columns; left pixel = columns 0..4, right pixel = columns 1..5
 DEVI void median25_pair(const float w[5][6], float& ml, float& mr) {
     float v[25], u[25];
@@ -442,6 +456,11 @@ DEVI void median25_run4(const float w[5][8], float& m0, float& m1, float& m2, fl
 }
 #undef CE1
 #undef S31
+#undef MN2
+#undef MX2
+#undef MN3
+#undef MX3
+#undef MD3
 }  // namespace
 
 struct MedParams {

@@ -105,13 +105,30 @@ for wi, m in enumerate(meds):
     assert val[m] == ge13, f"window {wi} is not a median network"
 print("all four windows verified on 2^25 binary inputs each")
 
-# ---- emit
+# ---- fuse what is left: min(min(a, b), c) with a single-use inner min is one v_min3 (likewise max).  Semantics are unchanged
+# (the verification above ran on the unfused graph and min3 = min o min), so this only rewrites the emission.
+live = sorted(g.live(meds))
+uses = {}
+for x in live:
+    if g.n[x][0] != 'in':
+        for y in g.n[x][1:]: uses[y] = uses.get(y, 0) + 1
+for m in meds: uses[m] = uses.get(m, 0) + 1
+fused_away = set()
+for x in live:
+    t = g.n[x]
+    if t[0] in ('min', 'max'):
+        for i in (1, 2):
+            y = t[i]
+            if g.n[y][0] == t[0] and uses.get(y, 0) == 1 and y not in fused_away:
+                g.n[x] = (t[0] + '3', g.n[y][1], g.n[y][2], t[3 - i])
+                fused_away.add(y)
+                break
 live = sorted(g.live(meds))
 nops = sum(1 for x in live if g.n[x][0] != 'in')
 name = {}
 lines = ["// GENERATED by tools/gen_median_run4.py (verified exhaustively there) -- do not edit.",
          "// in:  float w[5][8] (rows x columns of the window);  out: float m0, m1, m2, m3 = medians of columns 0-4, 1-5, 2-6, 3-7.",
-         f"// {nops} min/max/min3/med3/max3 operations (the compiler fuses further min(min(a,b),c) chains)."]
+         f"// {nops} min/max/min3/med3/max3 operations."]
 for x in live:
     t = g.n[x]
     if t[0] == 'in':
@@ -119,8 +136,9 @@ for x in live:
         continue
     name[x] = f"t{x}"
     a = [name[y] for y in t[1:]]
-    expr = {'min': "fminf({}, {})", 'max': "fmaxf({}, {})", 'min3': "fminf(fminf({}, {}), {})", 'max3': "fmaxf(fmaxf({}, {}), {})",
-            'med3': "__builtin_amdgcn_fmed3f({}, {}, {})"}[t[0]].format(*a)
+    # MN2 / MX2 / MN3 / MX3 / MD3 are defined by the including file (k_ahd.hip: raw v_min / v_max / v_min3 / v_max3 / v_med3)
+    expr = {'min': "MN2({}, {})", 'max': "MX2({}, {})", 'min3': "MN3({}, {}, {})", 'max3': "MX3({}, {}, {})",
+            'med3': "MD3({}, {}, {})"}[t[0]].format(*a)
     lines.append(f"const float t{x} = {expr};")
 for i, m in enumerate(meds):
     lines.append(f"m{i} = {name[m]};")
