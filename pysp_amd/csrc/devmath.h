@@ -126,13 +126,23 @@ DEVI int dot2_i16(unsigned v, int w, int acc) {
     typedef short s2 __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, v), __builtin_bit_cast(s2, w), acc, false);
 }
+// v_mul_u32_u24 spelled out: the compiler turns __umul24 back into a plain multiply and then cannot prove (16 - f) | (f << 16) is a
+// 24-bit value, so it picks v_mul_lo_u32, which issues at a quarter of the rate
+DEVI unsigned mul24(unsigned a, unsigned b) { unsigned d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B, float& L, float& a, float& b) {
-    const int cx = (int)__builtin_rintf(clip01_cv(R) * 16384.0f), cy = (int)__builtin_rintf(clip01_cv(G) * 16384.0f), cz = (int)__builtin_rintf(clip01_cv(B) * 16384.0f);
-    const int fx = (cx >> 5) & 15, fy = (cy >> 5) & 15, fz = (cz >> 5) & 15;
-    const uint4* e = lut + 4 * (((cz >> 9) * CV410_DIM + (cy >> 9)) * CV410_DIM + (cx >> 9));
+    // cvRound(clip(v) * 2^14) without a conversion: clip(v) * 2^14 + 1.5 * 2^23 is one exact-product FMA whose rounding IS round-half-even
+    // to an integer, and the integer (<= 2^14) then sits in the low mantissa bits: cell = bits 9..14, position = bits 5..8.
+    const unsigned bx = __float_as_uint(__builtin_fmaf(clip01_cv(R), 16384.0f, 12582912.0f));
+    const unsigned by = __float_as_uint(__builtin_fmaf(clip01_cv(G), 16384.0f, 12582912.0f));
+    const unsigned bz = __float_as_uint(__builtin_fmaf(clip01_cv(B), 16384.0f, 12582912.0f));
+    const unsigned fx = (bx >> 5) & 15u, fy = (by >> 5) & 15u, fz = (bz >> 5) & 15u;
+    const unsigned tx = (bx >> 9) & 63u, ty = (by >> 9) & 63u, tz = (bz >> 9) & 63u;
+    // 24-bit multiplies throughout (v_mul_u32_u24 / v_mad_u32_u24 issue at the full rate, v_mul_lo_u32 at a quarter of it)
+    const uint4* e = lut + 4u * (__umul24(__umul24(tz, CV410_DIM) + ty, CV410_DIM) + tx);
     const uint4 q0 = e[0], q1 = e[1], q2 = e[2];      // 12 dwords of one 64-byte line: (dz, dy) = (0,0), (0,1), (1,0), (1,1), each (L, a, b) as x pairs
-    const int wx = (16 - fx) | (fx << 16);                                   // both x weights in one register; times <= 256 stays inside each half
-    const int w00 = wx * ((16 - fy) * (16 - fz)), w10 = wx * (fy * (16 - fz)), w01 = wx * ((16 - fy) * fz), w11 = wx * (fy * fz);   // (dy, dz)
+    const unsigned wx = (16u - fx) | (fx << 16);                             // both x weights in one register; times <= 256 stays inside each half
+    const int w00 = (int)mul24(wx, mul24(16u - fy, 16u - fz)), w10 = (int)mul24(wx, mul24(fy, 16u - fz));   // (dy, dz)
+    const int w01 = (int)mul24(wx, mul24(16u - fy, fz)), w11 = (int)mul24(wx, mul24(fy, fz));
     int aL = dot2_i16(q2.y, w11, dot2_i16(q1.z, w01, dot2_i16(q0.w, w10, dot2_i16(q0.x, w00, 0))));
     int aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 0))));
     int ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 0))));
