@@ -88,6 +88,13 @@ DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool a
 // (d*d == (-d)*(-d) bit for bit), so only the other six window cells are tested.
 // (Measured and dropped: evaluating the six pixel pairs inside the quad once for both of their pixels saves 36 of
 // ~240 operations per direction but costs 12-16 VGPRs: 3-25 % slower at 165 VGPRs, +-0.5 % at 137 (SLP threshold 20).)
+// c + (lane's bit of m): the two compares of a cell leave their results in scalar register pairs, their AND is a scalar instruction, and
+// v_addc_co_u32 takes such a pair as its carry-in -- one vector instruction per cell instead of v_cndmask(0, 1) + v_add
+DEVI int add_lane_bit(int c, unsigned long long m) {
+    int d; unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(carry_out) : "v"(c), "s"(m));
+    return d;
+}
 template <int DIR>
 DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
 #pragma unroll
@@ -98,7 +105,11 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
         float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
         float da1 = ra - wa[n1y][n1x], db1 = rb - wq[n1y][n1x], da2 = ra - wa[n2y][n2x], db2 = rb - wq[n2y][n2x];
         float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
-        float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
+        // Cython's max(a, b) = (b > a) ? b : a.  Here every operand is finite and non-negative (this form only runs where Lab is finite:
+        // the HDR metric, whose L may not be, takes the literal form below), so one raw v_max_f32 returns the same bits as compare + select.
+        float el, ec;
+        asm("v_max_f32 %0, %1, %2" : "=v"(el) : "v"(e1), "v"(e2));
+        asm("v_max_f32 %0, %1, %2" : "=v"(ec) : "v"(c1), "v"(c2));
         int c = 3;
 #pragma unroll
         for (int wy = 0; wy < 3; wy++)
@@ -107,8 +118,7 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
                 const int y = dy + wy, x = dx + wx;
                 if ((y == cy && x == cx) || (y == n1y && x == n1x) || (y == n2y && x == n2x)) continue;
                 float da = wa[y][x] - ra, db = wq[y][x] - rb;
-                bool ok = (wl[y][x] - rl <= el) && (da * da + db * db <= ec);
-                c += ok ? 1 : 0;
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(wl[y][x] - rl <= el) & __builtin_amdgcn_ballot_w64(da * da + db * db <= ec));
             }
         cnt[k] = c;
     }
@@ -135,8 +145,7 @@ DEVI void vote_quad_literal(const float wl[4][4], const float wa[4][4], const fl
             for (int wx = 0; wx < 3; wx++) {
                 const int y = dy + wy, x = dx + wx;
                 float da = wa[y][x] - ra, db = wq[y][x] - rb;
-                bool ok = (wl[y][x] - rl <= el) && (da * da + db * db <= ec);
-                c += ok ? 1 : 0;
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(wl[y][x] - rl <= el) & __builtin_amdgcn_ballot_w64(da * da + db * db <= ec));
             }
         cnt[k] = c;
     }
