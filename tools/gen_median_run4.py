@@ -2,7 +2,8 @@
 """Generates pysp_amd/csrc/median25_run4.inc: the 5x5 medians of four horizontally adjacent pixels from one 5x8 window.
 
 Scheme (all min/max, so the 0-1 principle applies; verified here on all 2^25 binary inputs of every window before the file is written):
-  * the eight window columns are sorted (9-exchange network, three of them as one min3/med3/max3 group);
+  * the eight window columns are sorted by insertion: min3/med3/max3 of three, then two insertions, where rank i of
+    (sorted s) + x is med3(s[i-1], s[i], x) -- 12 operations per column;
   * neighbouring sorted columns are merged pairwise (Batcher odd-even merge): A = c1|c2, B = c3|c4, C = c5|c6;
   * a pixel pair shares four columns = two merged lists; of their union only the ranks 8..13 can be the median of a window
     that adds five more samples, so only those six ranks of merge(A,B) / merge(B,C) are produced (pruned odd-even merge);
@@ -38,14 +39,14 @@ class G:
             if self.n[x][0] != 'in': st += list(self.n[x][1:])
         return L
 
+def insert(g, s, x):
+    """sorted s + one element: rank i of the result is clamp(x, s[i-1], s[i]) = med3 -- one operation per output"""
+    return [g.mn(s[0], x)] + [g.op('med3', s[i - 1], s[i], x) for i in range(1, len(s))] + [g.mx(s[-1], x)]
+
 def sort5(g, v):
-    v = list(v)
-    v[0], v[1] = g.mn(v[0], v[1]), g.mx(v[0], v[1])
-    a, b, c = v[2], v[3], v[4]
-    v[2], v[3], v[4] = g.op('min3', a, b, c), g.op('med3', a, b, c), g.op('max3', a, b, c)
-    for i, j in ((1, 4), (0, 3), (0, 2), (1, 3), (1, 2)):
-        v[i], v[j] = g.mn(v[i], v[j]), g.mx(v[i], v[j])
-    return v
+    a, b, c = v[0], v[1], v[2]
+    s = [g.op('min3', a, b, c), g.op('med3', a, b, c), g.op('max3', a, b, c)]
+    return insert(g, insert(g, s, v[3]), v[4])          # 3 + 4 + 5 = 12 operations (9 exchanges would be 18)
 
 def merge(g, A, B, W):
     w = [INF] * W
