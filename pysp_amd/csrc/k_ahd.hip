@@ -397,28 +397,26 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 // ================================================================================================
 // Kernel B: one chroma post-process stage (ahd.py:148-161) + optional colour tail.
 //   r' = med5(r-g)+g ; b' = med5(b-g)+g ; g' = (med5(g-r') + med5(g-b') + r' + b') / 2
-// cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.  Tile 32x32 px, halo 4 px.
+// cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.
 namespace {
-#ifndef MED_BTX
-#define MED_BTX 32                               // measured (24 MP, 1 stage), with r', b' of the interior kept in registers:
-#define MED_BTY 32                               // 32x32 px / 256 threads (29.6 KB LDS, 5 workgroups per CU) 0.389 ms;
-#define MED_NT 256                               // 64x32 / 512 (54 KB, 2 per CU) 0.394; before, with r', b' in LDS: 0.402-0.410
-#endif
-constexpr int BTX = MED_BTX, BTY = MED_BTY;
-constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // r-g, b-g planes (halo 4)
-constexpr int B2X = BTX + 4, B2Y = BTY + 4;     // g-r', g-b' planes (halo 2)
-constexpr int NT_B = MED_NT;
+// Geometry (measured history in DESIGN.md 7.1).  A workgroup produces 60x28 px.  Its first-level region (the tile + the halo of 2 the
+// second level reads) is 64x32 px = 256 runs of eight pixels, exactly one per thread, and every thread later computes the second level
+// on the SAME eight pixels, so r', b' never leave its registers; the runs at the left / right edge of the tile carry two pixels of halo
+// whose second-level medians are simply not used.  Round 2's first geometry (32x32 px, runs of four, the 272-px halo ring done in
+// pixel pairs by half of the waves) issued 5.3 network operations per wave and output pixel; this one 4.5.
+constexpr int BTX = 60, BTY = 28;                // output tile
+constexpr int RX = BTX + 4, RY = BTY + 4;        // first-level region
+constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // g, r-g, b-g planes (halo 4); row stride 68 floats: rows of 8-float runs alternate bank halves
+constexpr int DPAD = 4, DST = RX + DPAD;         // g-r', g-b' planes: region column c is stored at DPAD + c (16-byte aligned runs); a window that
+                                                 // starts two columns left of the region reads the pad / the previous row's tail: halo-only medians
+constexpr int NT_B = 256;
+static_assert((RX / 8) * RY == NT_B, "one run of eight per thread");
 
-// Median of 25 by a selection network (exact; order independent): the classic 99-exchange network;
-// wherever three exchanges (b,c),(a,c),(a,b) fully sort a triple they are issued as one v_min3 / v_med3 /
-// v_max3 group (3 VALU ops instead of 6; on gfx950 min/max/med3 issue at 4 cycles per wave, so the
-// count of these ops is what bounds the kernel).  Exhaustive 0-1 check: tools/check_median25.c.
-// The kernel always handles a horizontally adjacent pixel pair: the two 5x5 windows share 20 elements, the
-// 13 exchanges that involve only those are evaluated once (-17 % ops), the rest runs on both in lockstep.
-// The networks are spelled with raw VALU instructions: fminf / fmaxf are llvm.minnum / maxnum, for which the backend (IEEE mode) first
-// canonicalises every operand it cannot prove quiet -- one extra v_max_f32 x, x per value loaded from LDS, 76 of the stage's 2 478
-// vector instructions.  A signalling NaN is the only input the two forms treat differently, and those are outside the contract
-// (DESIGN.md section 6).  Plain (non-volatile) asm with register operands: the compiler schedules and allocates around it as usual.
+// Median of 25 by selection networks over min / max / med3 (exact; order independent).  The networks are spelled with raw VALU
+// instructions: fminf / fmaxf are llvm.minnum / maxnum, for which the backend (IEEE mode) first canonicalises every operand it
+// cannot prove quiet -- one extra v_max_f32 x, x per value loaded from LDS.  A signalling NaN is the only input the two forms
+// treat differently, and those are outside the contract.  Plain (non-volatile) asm with register operands:
+// the compiler schedules and allocates around it as usual.
 DEVI float vmin2(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 DEVI float vmax2(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 DEVI float vmin3(float a, float b, float c) { float d; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
@@ -429,42 +427,15 @@ DEVI float vmed3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %
 #define MN3(a, b, c) vmin3(a, b, c)
 #define MX3(a, b, c) vmax3(a, b, c)
 #define MD3(a, b, c) vmed3(a, b, c)
-#define CE1(v, a, b) { float _t = MN2(v[a], v[b]); v[b] = MX2(v[a], v[b]); v[a] = _t; }
-#define S31(v, a, b, c) { float _lo = MN3(v[a], v[b], v[c]); float _hi = MX3(v[a], v[b], v[c]); \
-                          float _md = MD3(v[a], v[b], v[c]); v[a] = _lo; v[b] = _md; v[c] = _hi; }
-// w: 5 rows x 6 columns; left pixel = columns 0..4, right pixel = columns 1..5
-DEVI void median25_pair(const float w[5][6], float& ml, float& mr) {
-    float v[25], u[25];
-#pragma unroll
-    for (int dy = 0; dy < 5; dy++) {
-#pragma unroll
-        for (int dx = 0; dx < 4; dx++) v[dy * 4 + dx] = w[dy][dx + 1];   // wires 0..19: the shared columns
-        v[20 + dy] = w[dy][0];
-    }
-#define CE(a, b) CE1(v, a, b)
-#define S3(a, b, c) S31(v, a, b, c)
-#include "median25_shared.inc"
-#undef CE
-#undef S3
-#pragma unroll
-    for (int k = 0; k < 20; k++) u[k] = v[k];
-#pragma unroll
-    for (int dy = 0; dy < 5; dy++) u[20 + dy] = w[dy][5];
-#define CE(a, b) { CE1(v, a, b) CE1(u, a, b) }
-#define S3(a, b, c) { S31(v, a, b, c) S31(u, a, b, c) }
-#include "median25_rest.inc"
-#undef CE
-#undef S3
-    ml = v[12]; mr = u[12];
+// The medians of eight horizontally adjacent pixels from one 5x12 window: columns sorted by med3 insertion, neighbouring columns merged
+// pairwise and shared by up to four windows, of a pixel pair's 20 common samples only the six ranks that a fifth column can still turn
+// into the median (tools/gen_median_run.py builds the network and verifies every window on all 2^25 binary inputs): 468 operations,
+// 58.5 per median, against 98 for the classic 99-exchange network with shared triples.
+DEVI void median25_run8(const float w[5][12], float m[8]) {
+    float m0, m1, m2, m3, m4, m5, m6, m7;
+#include "median25_run8.inc"
+    m[0] = m0; m[1] = m1; m[2] = m2; m[3] = m3; m[4] = m4; m[5] = m5; m[6] = m6; m[7] = m7;
 }
-// The medians of four horizontally adjacent pixels from one 5x8 window: sorted columns, pairwise merges shared by the
-// windows, only the ranks a fifth column can still turn into the median (tools/gen_median_run4.py builds the network and
-// verifies every window on all 2^25 binary inputs): 72 operations per median against 98 for the pairwise network.
-DEVI void median25_run4(const float w[5][8], float& m0, float& m1, float& m2, float& m3) {
-#include "median25_run4.inc"
-}
-#undef CE1
-#undef S31
 #undef MN2
 #undef MX2
 #undef MN3
@@ -477,54 +448,59 @@ struct MedParams {
     float* out;        // (H,W,3)
     int H, W;
     int tail;
+    int vec;           // W % 4 == 0 and both images 16-byte aligned: 16-byte global accesses
     Ccm ccm;
 };
 
-// Window of a horizontally adjacent pixel pair: 5 rows x 6 columns starting at an even column -> three
-// 8-byte LDS reads per row.
-DEVI void load_pair_window(const float* plane, int stride, int ly, int lx, float w[5][6]) {
-#pragma unroll
-    for (int dy = 0; dy < 5; dy++) {
-        const float2* row = reinterpret_cast<const float2*>(plane + (ly + dy) * stride + lx);
-        float2 a = row[0], b = row[1], c = row[2];
-        w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = c.x; w[dy][5] = c.y;
-    }
-}
-// Window of four horizontally adjacent pixels: 5 rows x 8 columns starting at an even column -> four 8-byte LDS reads per row.
-DEVI void load_run4_window(const float* plane, int stride, int ly, int lx, float w[5][8]) {
-#pragma unroll
-    for (int dy = 0; dy < 5; dy++) {
-        const float2* p = reinterpret_cast<const float2*>(plane + (ly + dy) * stride + lx);
-#pragma unroll
-        for (int q = 0; q < 4; q++) { float2 v = p[q]; w[dy][2 * q] = v.x; w[dy][2 * q + 1] = v.y; }
-    }
-}
-
 #ifndef MED_MIN_WAVES
-#define MED_MIN_WAVES 1                            // round 1: 104 VGPRs; forcing 5 waves (96 VGPRs, 5 spilled to scratch) measured 2 % faster, but the two-process
-                                                  // band test then failed: no kernel of this library uses scratch.  Round 2: 65 VGPRs, LDS-limited to five workgroups per
-                                                  // CU.  Measured and dropped: g-b' laid over the dead r-g plane (two first-level passes, one more barrier): 24.4 KB,
-                                                  // six workgroups per CU, 72 VGPRs -- 0.339 -> 0.343 ms: the stage is bound by instruction issue, not by latency
+#define MED_MIN_WAVES 1                            // 46.9 KB of LDS: three workgroups per CU, registers are not the limit
 #endif
 __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedParams p) {
-    __shared__ __attribute__((aligned(16))) float s_g[B4Y][B4X], s_drg[B4Y][B4X], s_dbg[B4Y][B4X];   // g, r-g, b-g (halo 4)
-    __shared__ __attribute__((aligned(16))) float s_d1[B2Y][B2X], s_d2[B2Y][B2X];                     // g-r', g-b'  (halo 2)
+    // g, r-g, b-g (halo 4); the second level's inputs g-r', g-b' (halo 2) are laid over r-g, b-g once every thread is done with those:
+    // 29.4 KB, five workgroups per CU (the stage loses 16 % from three workgroups per CU to two)
+    __shared__ __attribute__((aligned(16))) float lds[3][B4Y][B4X];
+    float (*s_g)[B4X] = lds[0], (*s_drg)[B4X] = lds[1], (*s_dbg)[B4X] = lds[2];
+    float *s_d1 = &lds[1][0][0], *s_d2 = &lds[2][0][0];
+    static_assert(RY * DST + 4 <= B4Y * B4X, "a difference plane fits in the plane it replaces");
     const int tid = threadIdx.x, H = p.H, W = p.W;
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int tx0 = tbx * BTX, ty0 = tby * BTY;
 
-    {   // all global loads of a thread are issued before its first LDS store (they are in flight together)
+    // ---- load: all global loads of a thread are issued before its first LDS store (they are in flight together)
+    const bool inside = ty0 >= 4 && tx0 >= 4 && ty0 + BTY + 4 <= H && tx0 + BTX + 4 <= W;
+    if (inside && p.vec) {
+        // four pixels = 48 bytes = three 16-byte loads; the tile row starts on a 16-byte boundary (W, tx0 multiples of four)
+        constexpr int GPR = B4X / 4, NG = GPR * B4Y, NLG = (NG + NT_B - 1) / NT_B;
+        float4 t[NLG][3];
+#pragma unroll
+        for (int k = 0; k < NLG; k++) {
+            int gi = tid + k * NT_B;
+            if (gi >= NG) gi = NG - 1;
+            const int ly = gi / GPR, lg = gi - ly * GPR;
+            const float4* s = reinterpret_cast<const float4*>(p.in + ((size_t)(ty0 - 4 + ly) * W + (tx0 - 4 + 4 * lg)) * 3);
+            t[k][0] = s[0]; t[k][1] = s[1]; t[k][2] = s[2];
+        }
+#pragma unroll
+        for (int k = 0; k < NLG; k++) {
+            const int gi = tid + k * NT_B;
+            if (gi < NG) {
+                const int ly = gi / GPR, lx = 4 * (gi - ly * GPR);
+                const float4 a = t[k][0], b = t[k][1], c = t[k][2];      // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+                *reinterpret_cast<float4*>(&s_g[ly][lx]) = make_float4(a.y, b.x, b.w, c.z);
+                *reinterpret_cast<float4*>(&s_drg[ly][lx]) = make_float4(a.x - a.y, a.w - b.x, b.z - b.w, c.y - c.z);
+                *reinterpret_cast<float4*>(&s_dbg[ly][lx]) = make_float4(a.z - a.y, b.y - b.x, c.x - b.w, c.w - c.z);
+            }
+        }
+    } else {
         constexpr int NL = (B4Y * B4X + NT_B - 1) / NT_B;
-        const bool inside = ty0 >= 4 && tx0 >= 4 && ty0 + BTY + 4 <= H && tx0 + BTX + 4 <= W;
         float tr[NL], tg[NL], tb[NL];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             int idx = tid + k * NT_B;
             if (idx >= B4Y * B4X) idx = B4Y * B4X - 1;
             int ly = idx / B4X, lx = idx - ly * B4X;
-            int y = ty0 - 4 + ly, x = tx0 - 4 + lx;
-            if (!inside) { y = b_rep(y, H); x = b_rep(x, W); }       // uniform per workgroup: interior tiles skip the clamps
+            int y = b_rep(ty0 - 4 + ly, H), x = b_rep(tx0 - 4 + lx, W);
             const float* s = p.in + ((size_t)y * W + x) * 3;
             tr[k] = s[0]; tg[k] = s[1]; tb[k] = s[2];
         }
@@ -538,112 +514,105 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
         }
     }
     __syncthreads();
-    // First level: r' = med5(r-g)+g, b' = med5(b-g)+g and the second-level differences g-r', g-b' on the halo-2 region.
-    // W and the tile origin are even, so a pixel pair is inside or outside the image as a whole.  The tile's interior is done
-    // in runs of four pixels (median25_run4), one run per thread, the same run at both levels, so r', b' of the interior stay in
-    // registers and only the differences go to LDS; the halo-2 ring is shared out afterwards, in pixel pairs.
-    auto first_level_pair = [&](int oy, int ox) {   // (oy, ox): pair position in the halo-2 region
-        float w[5][6], m0, m1;
-        load_pair_window(&s_drg[0][0], B4X, oy, ox, w);
-        median25_pair(w, m0, m1);
-        float g0 = s_g[oy + 2][ox + 2], g1 = s_g[oy + 2][ox + 3];
-        float r0 = m0 + g0, r1 = m1 + g1;
-        load_pair_window(&s_dbg[0][0], B4X, oy, ox, w);
-        median25_pair(w, m0, m1);
-        float b0 = m0 + g0, b1 = m1 + g1;
-        *reinterpret_cast<float2*>(&s_d1[oy][ox]) = make_float2(g0 - r0, g1 - r1);
-        *reinterpret_cast<float2*>(&s_d2[oy][ox]) = make_float2(g0 - b0, g1 - b1);
-    };
-    constexpr int RUNS_X = BTX / 4, NRUN = BTY * RUNS_X, NCEN = NRUN / NT_B;
-    static_assert(BTX % 4 == 0 && NRUN % NT_B == 0, "every thread owns the same number of interior four-pixel runs");
-    float keep_r[NCEN][4], keep_b[NCEN][4];                         // r', b' of this thread's interior pixels
+
+    // ---- first level: r' = med5(r-g)+g, b' = med5(b-g)+g on this thread's run, the differences g-r', g-b' to LDS
+    const int oy = tid >> 3, ox = (tid & 7) * 8;                 // run position in the region (region (0,0) = image (ty0-2, tx0-2))
+    const int y = ty0 - 2 + oy, x0 = tx0 - 2 + ox;
+    float keep_r[8], keep_b[8], gg[8];
+    const bool first = y < H && x0 < W;                          // (rows above / columns left of the image are computed from the clamped
+    if (first) {                                                 //  planes like any other and replaced by the border pass below)
+        float w[5][12], m[8];
+        {
+            const float* gr = &s_g[oy + 2][ox];
+            const float2 ga = *reinterpret_cast<const float2*>(gr + 2), gd = *reinterpret_cast<const float2*>(gr + 8);
+            const float4 gb = *reinterpret_cast<const float4*>(gr + 4);
+            gg[0] = ga.x; gg[1] = ga.y; gg[2] = gb.x; gg[3] = gb.y; gg[4] = gb.z; gg[5] = gb.w; gg[6] = gd.x; gg[7] = gd.y;
+        }
+        auto window = [&](const float (*plane)[B4X]) {
 #pragma unroll
-    for (int k = 0; k < NCEN; k++) {
-        const int idx = tid + k * NT_B;
-        const int ly = idx / RUNS_X, lx = 4 * (idx - ly * RUNS_X);
-        const int oy = ly + 2, ox = lx + 2;
-        if (ty0 + ly < H && tx0 + lx < W) {
-            float w[5][8], m[4];
-            const float4 g4 = make_float4(s_g[oy + 2][ox + 2], s_g[oy + 2][ox + 3], s_g[oy + 2][ox + 4], s_g[oy + 2][ox + 5]);
-            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-            load_run4_window(&s_drg[0][0], B4X, oy, ox, w);
-            median25_run4(w, m[0], m[1], m[2], m[3]);
+            for (int dy = 0; dy < 5; dy++) {
+                const float4* r = reinterpret_cast<const float4*>(&plane[oy + dy][ox]);
 #pragma unroll
-            for (int q = 0; q < 4; q++) keep_r[k][q] = m[q] + gg[q];
-            load_run4_window(&s_dbg[0][0], B4X, oy, ox, w);
-            median25_run4(w, m[0], m[1], m[2], m[3]);
-#pragma unroll
-            for (int q = 0; q < 4; q++) keep_b[k][q] = m[q] + gg[q];
-            // the second pair of the run may lie beyond the right image border (W = 2 mod 4): its cells are then filled by the
-            // border pass below like every other outside position
-            const bool second = tx0 + lx + 2 < W;
-            *reinterpret_cast<float2*>(&s_d1[oy][ox]) = make_float2(gg[0] - keep_r[k][0], gg[1] - keep_r[k][1]);
-            *reinterpret_cast<float2*>(&s_d2[oy][ox]) = make_float2(gg[0] - keep_b[k][0], gg[1] - keep_b[k][1]);
-            if (second) {
-                *reinterpret_cast<float2*>(&s_d1[oy][ox + 2]) = make_float2(gg[2] - keep_r[k][2], gg[3] - keep_r[k][3]);
-                *reinterpret_cast<float2*>(&s_d2[oy][ox + 2]) = make_float2(gg[2] - keep_b[k][2], gg[3] - keep_b[k][3]);
+                for (int q = 0; q < 3; q++) { const float4 v = r[q]; w[dy][4 * q] = v.x; w[dy][4 * q + 1] = v.y; w[dy][4 * q + 2] = v.z; w[dy][4 * q + 3] = v.w; }
             }
-        }
+        };
+        window(s_drg);
+        median25_run8(w, m);
+#pragma unroll
+        for (int q = 0; q < 8; q++) keep_r[q] = m[q] + gg[q];
+        window(s_dbg);
+        median25_run8(w, m);
+#pragma unroll
+        for (int q = 0; q < 8; q++) keep_b[q] = m[q] + gg[q];
     }
-    {   // ring of the halo-2 region: rows 0,1 and B2Y-2,B2Y-1 in full, the two outer pairs of every other row
-        constexpr int NTB = 4 * (B2X / 2), NRING = NTB + 2 * BTY;
-        for (int t = tid; t < NRING; t += NT_B) {
-            int oy, ox;
-            if (t < NTB) { int r = t / (B2X / 2); oy = r < 2 ? r : B2Y - 4 + r; ox = 2 * (t - r * (B2X / 2)); }
-            else { int u = t - NTB; oy = 2 + (u >> 1); ox = (u & 1) ? B2X - 2 : 0; }
-            int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
-            if (y < 0 || y >= H || x < 0 || x >= W) continue;       // filled from the clamped position below
-            first_level_pair(oy, ox);
-        }
+    __syncthreads();
+    if (first) {
+        float4* d1 = reinterpret_cast<float4*>(&s_d1[oy * DST + DPAD + ox]);
+        float4* d2 = reinterpret_cast<float4*>(&s_d2[oy * DST + DPAD + ox]);
+        d1[0] = make_float4(gg[0] - keep_r[0], gg[1] - keep_r[1], gg[2] - keep_r[2], gg[3] - keep_r[3]);
+        d1[1] = make_float4(gg[4] - keep_r[4], gg[5] - keep_r[5], gg[6] - keep_r[6], gg[7] - keep_r[7]);
+        d2[0] = make_float4(gg[0] - keep_b[0], gg[1] - keep_b[1], gg[2] - keep_b[2], gg[3] - keep_b[3]);
+        d2[1] = make_float4(gg[4] - keep_b[4], gg[5] - keep_b[5], gg[6] - keep_b[6], gg[7] - keep_b[7]);
     }
     __syncthreads();
     // medianBlur replicates the border of ITS input plane: a position outside the image takes the values of
     // the clamped position (only tiles touching the image border have any).
     if (ty0 < 2 || tx0 < 2 || ty0 + BTY + 2 > H || tx0 + BTX + 2 > W) {
-        for (int idx = tid; idx < B2Y * B2X; idx += NT_B) {
-            int oy = idx / B2X, ox = idx - oy * B2X;
-            int y = ty0 - 2 + oy, x = tx0 - 2 + ox;
-            if (y >= 0 && y < H && x >= 0 && x < W) continue;
-            int cy = b_rep(y, H) - (ty0 - 2), cx = b_rep(x, W) - (tx0 - 2);
-            if (cy < 0 || cy >= B2Y || cx < 0 || cx >= B2X) continue;     // beyond a partial tile: never consumed
-            s_d1[oy][ox] = s_d1[cy][cx]; s_d2[oy][ox] = s_d2[cy][cx];
+        for (int idx = tid; idx < RY * RX; idx += NT_B) {
+            const int py = idx / RX, px = idx - py * RX;
+            const int yy = ty0 - 2 + py, xx = tx0 - 2 + px;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) continue;
+            const int cy = b_rep(yy, H) - (ty0 - 2), cx = b_rep(xx, W) - (tx0 - 2);
+            if (cy < 0 || cy >= RY || cx < 0 || cx >= RX) continue;     // beyond a partial tile: never consumed
+            s_d1[py * DST + DPAD + px] = s_d1[cy * DST + DPAD + cx]; s_d2[py * DST + DPAD + px] = s_d2[cy * DST + DPAD + cx];
         }
         __syncthreads();
     }
-    // Second level: g' = (med5(g-r') + med5(g-b') + r' + b') / 2, colour tail, store
+    // ---- second level on the same run: g' = (med5(g-r') + med5(g-b') + r' + b') / 2, colour tail, store
+    const int qlo = ox == 0 ? 2 : 0;                              // pixels [qlo, qhi) of the run belong to this tile and to the image
+    const int qhi = min(ox == RX - 8 ? 6 : 8, W - x0);
+    if (oy < 2 || oy >= RY - 2 || y >= H || qhi <= qlo) return;
+    float ma[8], mb[8];
+    {
+        float w[5][12];
+        auto window = [&](const float* plane) {
 #pragma unroll
-    for (int k = 0; k < NCEN; k++) {
-        const int idx = tid + k * NT_B;
-        const int ly = idx / RUNS_X, lx = 4 * (idx - ly * RUNS_X);
-        const int y = ty0 + ly, x = tx0 + lx;
-        if (y >= H || x >= W) continue;
-        float w[5][8], ma[4], mb[4];
-        load_run4_window(&s_d1[0][0], B2X, ly, lx, w);
-        median25_run4(w, ma[0], ma[1], ma[2], ma[3]);
-        load_run4_window(&s_d2[0][0], B2X, ly, lx, w);
-        median25_run4(w, mb[0], mb[1], mb[2], mb[3]);
-        float gq[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) gq[q] = (((ma[q] + mb[q]) + keep_r[k][q]) + keep_b[k][q]) / 2.0f;
-        float* dst = p.out + ((size_t)y * W + x) * 3;
-        if (!(W & 3)) {
-            // W % 4 == 0: the run's 48 bytes are 16-byte aligned and wholly inside the image -> three 16-byte stores, each issued as soon
-            // as its floats exist (pixel by pixel: the float64 tails of four pixels do not pile up in registers)
-            float o[12];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float r = keep_r[k][q], g = gq[q], b = keep_b[k][q];
-                colour_tail(p.tail, p.ccm.m, r, g, b);
-                o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
-                if (q >= 1) reinterpret_cast<float4*>(dst)[q - 1] = make_float4(o[4 * q - 4], o[4 * q - 3], o[4 * q - 2], o[4 * q - 1]);
+            for (int dy = 0; dy < 5; dy++) {
+                const float* r = plane + (oy - 2 + dy) * DST + DPAD + ox - 2;       // 8-byte aligned
+                const float2 a = *reinterpret_cast<const float2*>(r), d = *reinterpret_cast<const float2*>(r + 10);
+                const float4 b = *reinterpret_cast<const float4*>(r + 2), c = *reinterpret_cast<const float4*>(r + 6);
+                w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = b.z; w[dy][5] = b.w;
+                w[dy][6] = c.x; w[dy][7] = c.y; w[dy][8] = c.z; w[dy][9] = c.w; w[dy][10] = d.x; w[dy][11] = d.y;
             }
-        } else {
+        };
+        window(s_d1);
+        median25_run8(w, ma);
+        window(s_d2);
+        median25_run8(w, mb);
+    }
+    float* dst = p.out + ((size_t)y * W + x0) * 3;
+    // 16-byte stores where the image allows: the run's 96 bytes start 8 bytes past a 16-byte boundary -> 8 + 5 x 16 + 8 bytes, each store
+    // issued as soon as its floats exist (pixel by pixel: the float64 tails of eight pixels do not pile up in registers); edge runs
+    // leave out their halo pixels
+    const bool vst = p.vec && x0 + 8 <= W;
+    float o[24];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (q >= 2 && x + 2 >= W) break;         // the second pair only if it is inside the image
-                float r = keep_r[k][q], g = gq[q], b = keep_b[k][q];
-                colour_tail(p.tail, p.ccm.m, r, g, b);
-                dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b;
+    for (int q = 0; q < 8; q++) {
+        if (q >= qlo && q < qhi) {
+            float r = keep_r[q], b = keep_b[q], g = (((ma[q] + mb[q]) + r) + b) / 2.0f;
+            colour_tail(p.tail, p.ccm.m, r, g, b);
+            o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
+            if (!vst) { dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b; }
+        }
+        if (vst) {
+            if (q == 0 && qlo == 0) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+            if (q == 1 && qlo == 0) *reinterpret_cast<float4*>(dst + 2) = make_float4(o[2], o[3], o[4], o[5]);
+            if (q == 3) *reinterpret_cast<float4*>(dst + 6) = make_float4(o[6], o[7], o[8], o[9]);
+            if (q == 4) *reinterpret_cast<float4*>(dst + 10) = make_float4(o[10], o[11], o[12], o[13]);
+            if (q == 5) *reinterpret_cast<float4*>(dst + 14) = make_float4(o[14], o[15], o[16], o[17]);
+            if (q == 7 && qhi == 8) {
+                *reinterpret_cast<float4*>(dst + 18) = make_float4(o[18], o[19], o[20], o[21]);
+                *reinterpret_cast<float2*>(dst + 22) = make_float2(o[22], o[23]);
             }
         }
     }
@@ -685,6 +654,7 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
         bool last = s == stages - 1;
         m.out = last ? d_out : bufs[(s + 1) & 1];
         m.tail = last ? tail : 0;
+        m.vec = !(W & 3) && !((reinterpret_cast<uintptr_t>(m.in) | reinterpret_cast<uintptr_t>(m.out)) & 15);
         if (tl) tl->begin(st, "k_ahd_median_stage");
         hipLaunchKernelGGL(k_ahd_median_stage, gb, dim3(NT_B), 0, st, m);
         if (tl) tl->end(st);

@@ -61,20 +61,24 @@ def sel(g, S, T):
     m = g.op('min3', terms[0], terms[1], terms[2])
     return g.mn(m, g.op('min3', terms[3], terms[4], terms[5]))
 
+NRUN = int(os.environ.get("RUN", "8"))      # medians per call: 4 (5x8 window) or 8 (5x12 window)
+assert NRUN % 2 == 0
 g = G()
-# construction order = emission order: a sliding order keeps few values alive (two merged lists, one middle set, one spare column)
+# construction order = emission order: a sliding order keeps few values alive (two merged lists, one middle set, the odd columns still owed)
 col = lambda c: sort5(g, [g.inp((c, r)) for r in range(5)])
-sc = {}
-sc[1], sc[2] = col(1), col(2); A = merge(g, sc[1], sc[2], 16)
-sc[3], sc[4] = col(3), col(4); B = merge(g, sc[3], sc[4], 16)
-S01 = merge(g, A, B, 32)[7:13]
-sc[0] = col(0); m0 = sel(g, S01, sc[0])
-sc[5] = col(5); m1 = sel(g, S01, sc[5])
-sc[6] = col(6); C = merge(g, sc[5], sc[6], 16)
-S23 = merge(g, B, C, 32)[7:13]
-m2 = sel(g, S23, sc[2])
-sc[7] = col(7); m3 = sel(g, S23, sc[7])
-meds = [m0, m1, m2, m3]
+sc, P, S, meds = {}, {}, {}, []
+def pair(j):            # P[j] = columns 2j+1 | 2j+2 merged
+    for c in (2 * j + 1, 2 * j + 2):
+        if c not in sc: sc[c] = col(c)
+    P[j] = merge(g, sc[2 * j + 1], sc[2 * j + 2], 16)
+pair(0)
+for j in range(NRUN // 2):          # windows 2j (= column 2j + P[j] + P[j+1]) and 2j+1 (= P[j] + P[j+1] + column 2j+5)
+    pair(j + 1)
+    S[j] = merge(g, P[j], P[j + 1], 32)[7:13]
+    if j == 0: sc[0] = col(0)
+    meds.append(sel(g, S[j], sc[2 * j]))
+    if 2 * j + 5 not in sc: sc[2 * j + 5] = col(2 * j + 5)      # the last window's own column; otherwise sorted already as half of a pair
+    meds.append(sel(g, S[j], sc[2 * j + 5]))
 
 # ---- exhaustive 0-1 verification, bit-parallel over all 2^25 assignments of a window's inputs
 N = 25
@@ -104,7 +108,7 @@ for wi, m in enumerate(meds):
         for b in range(5): cnt[b], carry = cnt[b] ^ carry, cnt[b] & carry
     ge13 = (cnt[4] | (cnt[3] & cnt[2] & (cnt[1] | cnt[0]))) & FULL      # at least 13 of the 25 inputs are 1
     assert val[m] == ge13, f"window {wi} is not a median network"
-print("all four windows verified on 2^25 binary inputs each")
+print(f"all {NRUN} windows verified on 2^25 binary inputs each")
 
 # ---- fuse what is left: min(min(a, b), c) with a single-use inner min is one v_min3 (likewise max).  Semantics are unchanged
 # (the verification above ran on the unfused graph and min3 = min o min), so this only rewrites the emission.
@@ -127,8 +131,8 @@ for x in live:
 live = sorted(g.live(meds))
 nops = sum(1 for x in live if g.n[x][0] != 'in')
 name = {}
-lines = ["// GENERATED by tools/gen_median_run4.py (verified exhaustively there) -- do not edit.",
-         "// in:  float w[5][8] (rows x columns of the window);  out: float m0, m1, m2, m3 = medians of columns 0-4, 1-5, 2-6, 3-7.",
+lines = ["// GENERATED by tools/gen_median_run.py (verified exhaustively there) -- do not edit.",
+         f"// in:  float w[5][{NRUN + 4}] (rows x columns of the window);  out: float m0 .. m{NRUN - 1} = medians of columns 0-4, 1-5, ...",
          f"// {nops} min/max/min3/med3/max3 operations."]
 for x in live:
     t = g.n[x]
@@ -143,6 +147,6 @@ for x in live:
     lines.append(f"const float t{x} = {expr};")
 for i, m in enumerate(meds):
     lines.append(f"m{i} = {name[m]};")
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pysp_amd", "csrc", "median25_run4.inc")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pysp_amd", "csrc", f"median25_run{NRUN}.inc")
 open(out, "w").write("\n".join(lines) + "\n")
 print("wrote", out, nops, "operations")
