@@ -431,9 +431,15 @@ DEVI float vmed3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %
 // pairwise and shared by up to four windows, of a pixel pair's 20 common samples only the six ranks that a fifth column can still turn
 // into the median (tools/gen_median_run.py builds the network and verifies every window on all 2^25 binary inputs): 468 operations,
 // 58.5 per median, against 98 for the classic 99-exchange network with shared triples.
-DEVI void median25_run8(const float w[5][12], float m[8]) {
+// The window is loaded in pieces: the include calls MED_NEED(c) before the first use of column c (order 1 2 3 4 0 5 ... 11), and
+// need(c, w) fetches the piece that starts there, so the last columns are not held in registers while the first medians are computed.
+template <class Need>
+DEVI void median25_run8(Need need, float m[8]) {
+    float w[5][12];
     float m0, m1, m2, m3, m4, m5, m6, m7;
+#define MED_NEED(c) need(c, w);
 #include "median25_run8.inc"
+#undef MED_NEED
     m[0] = m0; m[1] = m1; m[2] = m2; m[3] = m3; m[4] = m4; m[5] = m5; m[6] = m6; m[7] = m7;
 }
 #undef MN2
@@ -521,27 +527,28 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     float keep_r[8], keep_b[8], gg[8];
     const bool first = y < H && x0 < W;                          // (rows above / columns left of the image are computed from the clamped
     if (first) {                                                 //  planes like any other and replaced by the border pass below)
-        float w[5][12], m[8];
+        float m[8];
         {
             const float* gr = &s_g[oy + 2][ox];
             const float2 ga = *reinterpret_cast<const float2*>(gr + 2), gd = *reinterpret_cast<const float2*>(gr + 8);
             const float4 gb = *reinterpret_cast<const float4*>(gr + 4);
             gg[0] = ga.x; gg[1] = ga.y; gg[2] = gb.x; gg[3] = gb.y; gg[4] = gb.z; gg[5] = gb.w; gg[6] = gd.x; gg[7] = gd.y;
         }
-        auto window = [&](const float (*plane)[B4X]) {
+        auto piece = [&](const float (*plane)[B4X]) {             // 16-byte aligned window: columns 0-3 | 4-7 | 8-11
+            return [=](int c, float w[5][12]) {
+                if (c != 1 && c != 4 && c != 8) return;
+                const int q = c >> 2;
 #pragma unroll
-            for (int dy = 0; dy < 5; dy++) {
-                const float4* r = reinterpret_cast<const float4*>(&plane[oy + dy][ox]);
-#pragma unroll
-                for (int q = 0; q < 3; q++) { const float4 v = r[q]; w[dy][4 * q] = v.x; w[dy][4 * q + 1] = v.y; w[dy][4 * q + 2] = v.z; w[dy][4 * q + 3] = v.w; }
-            }
+                for (int dy = 0; dy < 5; dy++) {
+                    const float4 v = reinterpret_cast<const float4*>(&plane[oy + dy][ox])[q];
+                    w[dy][4 * q] = v.x; w[dy][4 * q + 1] = v.y; w[dy][4 * q + 2] = v.z; w[dy][4 * q + 3] = v.w;
+                }
+            };
         };
-        window(s_drg);
-        median25_run8(w, m);
+        median25_run8(piece(s_drg), m);
 #pragma unroll
         for (int q = 0; q < 8; q++) keep_r[q] = m[q] + gg[q];
-        window(s_dbg);
-        median25_run8(w, m);
+        median25_run8(piece(s_dbg), m);
 #pragma unroll
         for (int q = 0; q < 8; q++) keep_b[q] = m[q] + gg[q];
     }
@@ -574,21 +581,28 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     if (oy < 2 || oy >= RY - 2 || y >= H || qhi <= qlo) return;
     float ma[8], mb[8];
     {
-        float w[5][12];
-        auto window = [&](const float* plane) {
+        auto piece = [&](const float* plane) {                     // window starts 8 bytes past a 16-byte boundary: columns 0-5 | 6-9 | 10-11
+            return [=](int c, float w[5][12]) {
+                if (c != 1 && c != 6 && c != 10) return;
 #pragma unroll
-            for (int dy = 0; dy < 5; dy++) {
-                const float* r = plane + (oy - 2 + dy) * DST + DPAD + ox - 2;       // 8-byte aligned
-                const float2 a = *reinterpret_cast<const float2*>(r), d = *reinterpret_cast<const float2*>(r + 10);
-                const float4 b = *reinterpret_cast<const float4*>(r + 2), c = *reinterpret_cast<const float4*>(r + 6);
-                w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = b.z; w[dy][5] = b.w;
-                w[dy][6] = c.x; w[dy][7] = c.y; w[dy][8] = c.z; w[dy][9] = c.w; w[dy][10] = d.x; w[dy][11] = d.y;
-            }
+                for (int dy = 0; dy < 5; dy++) {
+                    const float* r = plane + (oy - 2 + dy) * DST + DPAD + ox - 2;
+                    if (c == 1) {
+                        const float2 a = *reinterpret_cast<const float2*>(r);
+                        const float4 b = *reinterpret_cast<const float4*>(r + 2);
+                        w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = b.z; w[dy][5] = b.w;
+                    } else if (c == 6) {
+                        const float4 b = *reinterpret_cast<const float4*>(r + 6);
+                        w[dy][6] = b.x; w[dy][7] = b.y; w[dy][8] = b.z; w[dy][9] = b.w;
+                    } else {
+                        const float2 a = *reinterpret_cast<const float2*>(r + 10);
+                        w[dy][10] = a.x; w[dy][11] = a.y;
+                    }
+                }
+            };
         };
-        window(s_d1);
-        median25_run8(w, ma);
-        window(s_d2);
-        median25_run8(w, mb);
+        median25_run8(piece(s_d1), ma);
+        median25_run8(piece(s_d2), mb);
     }
     float* dst = p.out + ((size_t)y * W + x0) * 3;
     // 16-byte stores where the image allows: the run's 96 bytes start 8 bytes past a 16-byte boundary -> 8 + 5 x 16 + 8 bytes, each store

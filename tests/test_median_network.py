@@ -23,7 +23,7 @@ def test_median25_run_is_the_verified_generated_network(tmp_path, run):
     committed = open(os.path.join(ROOT, "pysp_amd", "csrc", f"median25_run{run}.inc")).read()
     assert open(out).read() == committed
     # interpret the emitted statements
-    stmts = [l for l in committed.splitlines() if l and not l.startswith("//")]
+    stmts = [l for l in committed.splitlines() if l and not l.startswith("//") and not l.startswith("MED_NEED")]
     rng = np.random.default_rng(3)
     for trial in range(20):
         w = rng.random((5, run + 4)).astype(np.float32) if trial else np.round(rng.random((5, run + 4)) * 3).astype(np.float32)   # ties too
