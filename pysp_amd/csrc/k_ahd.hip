@@ -534,14 +534,19 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
             const float4 gb = *reinterpret_cast<const float4*>(gr + 4);
             gg[0] = ga.x; gg[1] = ga.y; gg[2] = gb.x; gg[3] = gb.y; gg[4] = gb.z; gg[5] = gb.w; gg[6] = gd.x; gg[7] = gd.y;
         }
-        auto piece = [&](const float (*plane)[B4X]) {             // 16-byte aligned window: columns 0-3 | 4-7 | 8-11
+        auto piece = [&](const float (*plane)[B4X]) {             // 16-byte aligned window: columns 0-3, then pairs as they are needed
             return [=](int c, float w[5][12]) {
-                if (c != 1 && c != 4 && c != 8) return;
-                const int q = c >> 2;
+                if (c != 1 && !(c >= 4 && !(c & 1))) return;
 #pragma unroll
                 for (int dy = 0; dy < 5; dy++) {
-                    const float4 v = reinterpret_cast<const float4*>(&plane[oy + dy][ox])[q];
-                    w[dy][4 * q] = v.x; w[dy][4 * q + 1] = v.y; w[dy][4 * q + 2] = v.z; w[dy][4 * q + 3] = v.w;
+                    const float* r = &plane[oy + dy][ox];
+                    if (c == 1) {
+                        const float4 v = *reinterpret_cast<const float4*>(r);
+                        w[dy][0] = v.x; w[dy][1] = v.y; w[dy][2] = v.z; w[dy][3] = v.w;
+                    } else {
+                        const float2 v = *reinterpret_cast<const float2*>(r + c);
+                        w[dy][c] = v.x; w[dy][c + 1] = v.y;
+                    }
                 }
             };
         };
@@ -581,22 +586,19 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     if (oy < 2 || oy >= RY - 2 || y >= H || qhi <= qlo) return;
     float ma[8], mb[8];
     {
-        auto piece = [&](const float* plane) {                     // window starts 8 bytes past a 16-byte boundary: columns 0-5 | 6-9 | 10-11
+        auto piece = [&](const float* plane) {                     // window starts 8 bytes past a 16-byte boundary: columns 0-1, 2-5, then pairs
             return [=](int c, float w[5][12]) {
-                if (c != 1 && c != 6 && c != 10) return;
+                if (c != 1 && c != 2 && !(c >= 6 && !(c & 1))) return;
 #pragma unroll
                 for (int dy = 0; dy < 5; dy++) {
                     const float* r = plane + (oy - 2 + dy) * DST + DPAD + ox - 2;
-                    if (c == 1) {
-                        const float2 a = *reinterpret_cast<const float2*>(r);
+                    if (c == 2) {
                         const float4 b = *reinterpret_cast<const float4*>(r + 2);
-                        w[dy][0] = a.x; w[dy][1] = a.y; w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = b.z; w[dy][5] = b.w;
-                    } else if (c == 6) {
-                        const float4 b = *reinterpret_cast<const float4*>(r + 6);
-                        w[dy][6] = b.x; w[dy][7] = b.y; w[dy][8] = b.z; w[dy][9] = b.w;
+                        w[dy][2] = b.x; w[dy][3] = b.y; w[dy][4] = b.z; w[dy][5] = b.w;
                     } else {
-                        const float2 a = *reinterpret_cast<const float2*>(r + 10);
-                        w[dy][10] = a.x; w[dy][11] = a.y;
+                        const int c0 = c == 1 ? 0 : c;
+                        const float2 a = *reinterpret_cast<const float2*>(r + c0);
+                        w[dy][c0] = a.x; w[dy][c0 + 1] = a.y;
                     }
                 }
             };
