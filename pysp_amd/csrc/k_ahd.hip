@@ -525,8 +525,7 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     const int oy = tid >> 3, ox = (tid & 7) * 8;                 // run position in the region (region (0,0) = image (ty0-2, tx0-2))
     const int y = ty0 - 2 + oy, x0 = tx0 - 2 + ox;
     float keep_r[8], keep_b[8], gg[8];
-    const bool first = y < H && x0 < W;                          // (rows above / columns left of the image are computed from the clamped
-    if (first) {                                                 //  planes like any other and replaced by the border pass below)
+    {   // positions outside the image are computed from the clamped planes like any other and replaced by the border pass below
         float m[8];
         {
             const float* gr = &s_g[oy + 2][ox];
@@ -558,7 +557,7 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
         for (int q = 0; q < 8; q++) keep_b[q] = m[q] + gg[q];
     }
     __syncthreads();
-    if (first) {
+    {
         float4* d1 = reinterpret_cast<float4*>(&s_d1[oy * DST + DPAD + ox]);
         float4* d2 = reinterpret_cast<float4*>(&s_d2[oy * DST + DPAD + ox]);
         d1[0] = make_float4(gg[0] - keep_r[0], gg[1] - keep_r[1], gg[2] - keep_r[2], gg[3] - keep_r[3]);
@@ -614,12 +613,11 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     float o[24];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        if (q >= qlo && q < qhi) {
-            float r = keep_r[q], b = keep_b[q], g = (((ma[q] + mb[q]) + r) + b) / 2.0f;
-            colour_tail(p.tail, p.ccm.m, r, g, b);
-            o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
-            if (!vst) { dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b; }
-        }
+        // every pixel of the run goes through the tail, halo pixels of edge runs too (their lanes would idle otherwise, and an
+        // unconditionally defined o[] spares the register copies a conditional one costs); only the stores are predicated
+        float r = keep_r[q], b = keep_b[q], g = (((ma[q] + mb[q]) + r) + b) / 2.0f;
+        colour_tail(p.tail, p.ccm.m, r, g, b);
+        o[3 * q] = r; o[3 * q + 1] = g; o[3 * q + 2] = b;
         if (vst) {
             if (q == 0 && qlo == 0) *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
             if (q == 1 && qlo == 0) *reinterpret_cast<float4*>(dst + 2) = make_float4(o[2], o[3], o[4], o[5]);
@@ -630,6 +628,8 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
                 *reinterpret_cast<float4*>(dst + 18) = make_float4(o[18], o[19], o[20], o[21]);
                 *reinterpret_cast<float2*>(dst + 22) = make_float2(o[22], o[23]);
             }
+        } else if (q >= qlo && q < qhi) {
+            dst[3 * q] = r; dst[3 * q + 1] = g; dst[3 * q + 2] = b;
         }
     }
 }
