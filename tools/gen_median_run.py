@@ -8,8 +8,8 @@ inputs before the file is written):
   * neighbouring sorted columns are merged pairwise (Batcher odd-even merge): P0 = c1|c2, P1 = c3|c4, ... shared by up to four windows;
   * a pixel pair shares four columns = two merged lists; of their union only the ranks 8..13 can be the median of a window
     that adds five more samples, so only those six ranks of merge(Pj, Pj+1) are produced (pruned odd-even merge);
-  * a window's median is the 13th smallest of (those 20) + (its own fifth column T, sorted):
-        min(s13, max(s12,t1), max(s11,t2), max(s10,t3), max(s9,t4), max(s8,t5));
+  * a window's median is the 13th smallest of (those 20) + (its own fifth column T, sorted) = the median of the six kept ranks s8..s13
+    and t1..t5:  med3(s8, s13, med3(s9, t4, med3(s10, t3, med3(s11, t2, med3(s12, t1, t5))))) -- five operations;
   * resynthesis: every node of that graph is then matched, as a Boolean function of the window's 25 inputs, against
     min / max / min3 / max3 / med3 of all pairs and triples of nodes up to three levels below it (a clamp between two values whose
     order is implied by the network is one med3, ...), and a 0-1 programme picks the cheapest set of nodes that still produces the
@@ -62,9 +62,14 @@ def merge(g, A, B, W):
     return w[:len(A) + len(B)]
 
 def sel(g, S, T):
-    terms = [S[5]] + [g.mx(S[4 - j], T[j]) for j in range(5)]
-    m = g.op('min3', terms[0], terms[1], terms[2])
-    return g.mn(m, g.op('min3', terms[3], terms[4], terms[5]))
+    """median of 25 = 6th smallest of S[0..5] (ranks 8..13 of the shared 20, sorted) + T[0..4] (the fifth column, sorted): five nested
+    clamps (found by exhaustive search over formulas on sorted operands, tools/scratch is not needed to check it: the 0-1 verification
+    below covers it);  the min/max form min(s13, max(s12,t1), ..., max(s8,t5)) takes eight operations"""
+    m = g.op('med3', S[4], T[0], T[4])
+    m = g.op('med3', S[3], T[1], m)
+    m = g.op('med3', S[2], T[2], m)
+    m = g.op('med3', S[1], T[3], m)
+    return g.op('med3', S[0], S[5], m)
 
 NRUN = int(os.environ.get("RUN", "8"))      # medians per call: 4 (5x8 window) or 8 (5x12 window)
 assert NRUN % 2 == 0
