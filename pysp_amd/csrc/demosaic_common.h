@@ -106,9 +106,12 @@ DEVI void highpass_quad(const float W[4][4], float hf[4]) {
 // ---- finished RGB pixels of a quad -> global memory ---------------------------------------------------------------
 // Direct form: the quad's two rows as three 8-byte stores each (6 contiguous floats, 8-byte aligned because W is even).
 DEVI void store_quad_direct(float* out, int W, int qi, int qj, const float px[4][3]) {
+    // `out` is the (uniform) origin of the caller's tile and (qi, qj) the quad inside the tile: a 32-bit byte offset per lane, and the
+    // stores take (scalar base, vector offset) -- no 64-bit vector arithmetic
+    const unsigned rowbytes = (unsigned)W * 12u;
 #pragma unroll
     for (int dy = 0; dy < 2; dy++) {
-        float2* o = reinterpret_cast<float2*>(out + ((size_t)(2 * qi + dy) * W + 2 * qj) * 3);
+        float2* o = reinterpret_cast<float2*>(reinterpret_cast<char*>(out) + ((unsigned)(2 * qi + dy) * rowbytes + 24u * (unsigned)qj));
         o[0] = make_float2(px[2 * dy][0], px[2 * dy][1]);
         o[1] = make_float2(px[2 * dy][2], px[2 * dy + 1][0]);
         o[2] = make_float2(px[2 * dy + 1][1], px[2 * dy + 1][2]);
@@ -133,13 +136,17 @@ DEVI void stage_tile_store(float* stage, float* out, int W, int y0, int x0, int 
         o[2] = make_float2(px[2 * dy + 1][1], px[2 * dy + 1][2]);
     }
     __syncthreads();
+    // addresses: one 64-bit tile origin (uniform: scalar registers) + a tile-local 32-bit byte offset per lane -- the store takes
+    // the pair as (scalar base, vector offset), no 64-bit vector arithmetic (a tile spans < 2^32 bytes for any W the API accepts)
+    char* const tile = reinterpret_cast<char*>(out + ((size_t)y0 * W + x0) * 3);
+    const unsigned rowbytes = (unsigned)W * 12u;
 #pragma unroll
     for (int k = 0; k < (N4 + NTHREADS - 1) / NTHREADS; k++) {
         const int idx = threadIdx.x + k * NTHREADS;
         if (idx < N4) {
             const int row = idx / ROW4, c4 = idx - row * ROW4;
             const float4 v = *reinterpret_cast<const float4*>(stage + row * ROW + 4 * c4);
-            *reinterpret_cast<float4*>(out + ((size_t)(y0 + row) * W + x0) * 3 + 4 * c4) = v;
+            *reinterpret_cast<float4*>(tile + (mul24((unsigned)row, rowbytes) + 16u * (unsigned)c4)) = v;
         }
     }
 }

@@ -216,7 +216,11 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
                 qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
                 qj = TINY ? b_sym(qj, w) : b_sym1(qj, w);
             }
-            tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
+            if (!U16 && inside)     // uniform 64-bit tile origin + tile-local 32-bit byte offset: (scalar base, vector offset) loads
+                tmp[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.src.f32 + (size_t)(2 * (tq0y - 3)) * W + 2 * (tq0x - 3)) +
+                                                          (mul24((unsigned)ry, (unsigned)W * 4u) + 8u * (unsigned)mx));
+            else
+                tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
         }
 #pragma unroll
         for (int k = 0; k < NL; k++) {
@@ -390,7 +394,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             px[k][2] = rgbh[k][2] * c + rgbv[k][2] * nc;
             colour_tail(p.tail, M, px[k][0], px[k][1], px[k][2]);
         }
-        store_quad_direct(p.out, W, qi, qj, px);                       // two rows of three 8-byte stores instead of twelve dword stores
+        // two rows of three 8-byte stores instead of twelve dword stores; uniform tile origin + tile-local 32-bit offset (inner: lqy, lqx >= 1)
+        store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, lqy - 1, lqx - 1, px);
     }
 }
 
@@ -404,12 +409,15 @@ namespace {
 // on the SAME eight pixels, so r', b' never leave its registers; the runs at the left / right edge of the tile carry two pixels of halo
 // whose second-level medians are simply not used.  Round 2's first geometry (32x32 px, runs of four, the 272-px halo ring done in
 // pixel pairs by half of the waves) issued 5.3 network operations per wave and output pixel; this one 4.5.
-constexpr int BTX = 60, BTY = 28;                // output tile
+#ifndef MED_BTY
+#define MED_BTY 28
+#endif
+constexpr int BTX = 60, BTY = MED_BTY;           // output tile
 constexpr int RX = BTX + 4, RY = BTY + 4;        // first-level region
 constexpr int B4X = BTX + 8, B4Y = BTY + 8;     // g, r-g, b-g planes (halo 4); row stride 68 floats: rows of 8-float runs alternate bank halves
 constexpr int DPAD = 4, DST = RX + DPAD;         // g-r', g-b' planes: region column c is stored at DPAD + c (16-byte aligned runs); a window that
                                                  // starts two columns left of the region reads the pad / the previous row's tail: halo-only medians
-constexpr int NT_B = 256;
+constexpr int NT_B = (BTX + 4) / 8 * (BTY + 4);
 static_assert((RX / 8) * RY == NT_B, "one run of eight per thread");
 
 // Median of 25 by selection networks over min / max / med3 (exact; order independent).  The networks are spelled with raw VALU
@@ -472,19 +480,22 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int tx0 = tbx * BTX, ty0 = tby * BTY;
+    const unsigned rowbytes = (unsigned)W * 12u;
 
     // ---- load: all global loads of a thread are issued before its first LDS store (they are in flight together)
     const bool inside = ty0 >= 4 && tx0 >= 4 && ty0 + BTY + 4 <= H && tx0 + BTX + 4 <= W;
     if (inside && p.vec) {
         // four pixels = 48 bytes = three 16-byte loads; the tile row starts on a 16-byte boundary (W, tx0 multiples of four)
         constexpr int GPR = B4X / 4, NG = GPR * B4Y, NLG = (NG + NT_B - 1) / NT_B;
+        // uniform 64-bit tile origin + tile-local 32-bit byte offset per lane: (scalar base, vector offset) accesses, no 64-bit vector arithmetic
+        const char* const tile = reinterpret_cast<const char*>(p.in + ((size_t)(ty0 - 4) * W + (tx0 - 4)) * 3);
         float4 t[NLG][3];
 #pragma unroll
         for (int k = 0; k < NLG; k++) {
             int gi = tid + k * NT_B;
             if (gi >= NG) gi = NG - 1;
             const int ly = gi / GPR, lg = gi - ly * GPR;
-            const float4* s = reinterpret_cast<const float4*>(p.in + ((size_t)(ty0 - 4 + ly) * W + (tx0 - 4 + 4 * lg)) * 3);
+            const float4* s = reinterpret_cast<const float4*>(tile + (mul24((unsigned)ly, rowbytes) + 48u * (unsigned)lg));
             t[k][0] = s[0]; t[k][1] = s[1]; t[k][2] = s[2];
         }
 #pragma unroll
@@ -605,7 +616,9 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
         median25_run8(piece(s_d1), ma);
         median25_run8(piece(s_d2), mb);
     }
-    float* dst = p.out + ((size_t)y * W + x0) * 3;
+    // (row oy >= 2 here: the offset from the origin of region row 2, column 0 is non-negative; the two halo pixels left of the image's
+    // first column are addressed but never stored)
+    float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out + ((size_t)ty0 * W + (tx0 - 2)) * 3) + (mul24((unsigned)(oy - 2), rowbytes) + 12u * (unsigned)ox));
     // 16-byte stores where the image allows: the run's 96 bytes start 8 bytes past a 16-byte boundary -> 8 + 5 x 16 + 8 bytes, each store
     // issued as soon as its floats exist (pixel by pixel: the float64 tails of eight pixels do not pile up in registers); edge runs
     // leave out their halo pixels

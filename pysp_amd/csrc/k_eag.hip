@@ -43,12 +43,15 @@ static_assert(MWX % 2 == 0 && TQX % 2 == 0, "a mosaic tile row is a whole number
 template <bool TINY, bool U16>
 DEVI void mosaic_prefetch(const MosaicSrc& src, float4 tmp[NL4], int tid, int W, int h, int w, int tq0y, int tq0x, bool inside) {
     if (!U16 && inside && !(W & 3)) {
+        // uniform 64-bit tile origin + tile-local 32-bit byte offset per lane (scalar base, vector offset: no 64-bit vector arithmetic)
+        const char* const tile = reinterpret_cast<const char*>(src.f32 + (size_t)(2 * (tq0y - 2)) * W + 2 * (tq0x - 2));
+        const unsigned rowbytes = (unsigned)W * 4u;
 #pragma unroll
         for (int k = 0; k < NL4; k++) {
             int idx = tid + k * NT;
             if (idx >= NSLOT4) idx = NSLOT4 - 1;
             int ry = idx / (MWX / 2), m2 = idx - ry * (MWX / 2);
-            tmp[k] = *reinterpret_cast<const float4*>(src.f32 + (size_t)(2 * (tq0y - 2) + ry) * W + 2 * (tq0x - 2) + 4 * m2);
+            tmp[k] = *reinterpret_cast<const float4*>(tile + (mul24((unsigned)ry, rowbytes) + 16u * (unsigned)m2));
         }
     } else {
 #pragma unroll
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
         colour_tail(TAIL, p.ccm.m, r, g, b);
         px[k][0] = r; px[k][1] = g; px[k][2] = b;
     }
-    if (!staged) store_quad_direct(p.out, W, qi, qj, px);
+    if (!staged) store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, lqy, lqx, px);
     }
     if (staged) stage_tile_store<2 * TQX, 2 * TQY, NT>(lds, p.out, W, 2 * tq0y, 2 * tq0x, lqy, lqx, px);
 }
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(NT) k_draft(EagParams p) {
             }
             colour_tail(TAIL, p.ccm.m, px[k][0], px[k][1], px[k][2]);
         }
-        if (!staged) store_quad_direct(p.out, W, qi, qj, px);
+        if (!staged) store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, lqy, lqx, px);
     }
     if (staged) stage_tile_store<2 * TQX, 2 * TQY, NT>(lds, p.out, W, 2 * tq0y, 2 * tq0x, lqy, lqx, px);
 }
