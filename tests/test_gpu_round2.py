@@ -431,3 +431,38 @@ def test_lab_modes(orc, wbobj):
         ctx.set_lab_mode(1); pipe.ctx.set_lab_mode(1); orc.set_lab_mode(orc.DEFAULT_LAB_MODE)
     flips = np.mean((a != b).any(axis=-1))
     assert 0.005 < flips < 0.08, flips                 # the two restatements disagree on a few percent of the H/V decisions
+
+
+# ---- device pointers that are only float-aligned, and frame sizes on both sides of every tile edge ------------------------
+def test_unaligned_device_pointers_and_tile_edge_sizes(orc, wbobj):
+    """The kernels take 16-byte loads / stores where the image allows (W % 4 == 0 and, for the median stage, 16-byte aligned images);
+    a caller may hand over any float-aligned pointer (a slice of a larger buffer).  Results on views that start 4 bytes past a
+    16-byte boundary equal the aligned results bit for bit, and both equal the oracle, for sizes around the 60 x 28 px median tile,
+    the 28 x 28 px select tile and the 64 x 32 px EAG / Draft tile, W = 0 and 2 mod 4."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    wb, M = _wbM(orc)
+    pipe = DevicePipeline(0)
+    rng = np.random.default_rng(11)
+    sizes = [(28, 60), (30, 62), (56, 120), (58, 124), (26, 58), (84, 180), (62, 130), (34, 66)]
+    for H, W in sizes:
+        bay = rng.random((H, W), dtype=np.float32)
+        refs = {"ahd1": orc.pipeline_srgb(bay, wb, M, 2, False, 1, False), "ahd2_lin": orc.demosaic_ahd(bay, wb, M, False, 2),
+                "eag": orc.pipeline_srgb(bay, wb, M, 1, False, 0, False), "draft": orc.pipeline_srgb(bay, wb, M, 0, False, 0, False)}
+        for off in (0, 1):
+            src = torch.empty(H * W + 4, dtype=torch.float32, device="cuda")
+            d = src[off:off + H * W].view(H, W)
+            d.copy_(torch.from_numpy(bay))
+            buf = torch.full((H * W * 3 + 8,), -7.0, dtype=torch.float32, device="cuda")
+            out = buf[off:off + H * W * 3].view(H, W, 3)
+            assert (d.data_ptr() % 16 == 4 * off) and (out.data_ptr() % 16 == 4 * off)
+            got = {}
+            pipe.demosaic_to_srgb(d, wb, M, _lib.QUALITY_BEST, False, 1, False, out=out); pipe.sync(); got["ahd1"] = out.cpu().numpy().copy()
+            pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, False, 2, out=out); pipe.sync(); got["ahd2_lin"] = out.cpu().numpy().copy()
+            pipe.demosaic_to_srgb(d, wb, M, _lib.QUALITY_FAST, False, 0, False, out=out); pipe.sync(); got["eag"] = out.cpu().numpy().copy()
+            pipe.demosaic_to_srgb(d, wb, M, _lib.QUALITY_DRAFT, False, 0, False, out=out); pipe.sync(); got["draft"] = out.cpu().numpy().copy()
+            for k in refs:
+                assert np.array_equal(got[k], refs[k]), (H, W, off, k)
+            rest = buf.cpu().numpy()
+            assert (rest[:off] == -7.0).all() and (rest[off + H * W * 3:] == -7.0).all(), (H, W, off, "wrote outside the image")
