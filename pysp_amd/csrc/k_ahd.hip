@@ -16,7 +16,7 @@
 //       the Lab buffer lies over the by then dead mosaic and horizontal g/D planes
 //   finally
 //   P4  3x3 box of the packed votes (integer), H/V selection (both candidates still in registers), optional colour tail, store.
-// 92 VGPRs and 30.6 KB of LDS: five workgroups per CU.
+// 92-93 VGPRs; 20.6 KB of LDS with the Lab grid of mode 1 (read from L2), 30.6 KB with the closed-form tables of mode 0: five workgroups per CU.
 // Image-border rules (three of them coexist) are applied at true image edges only.
 #include "demosaic_common.h"
 #include "kernels.h"
@@ -410,7 +410,7 @@ namespace {
 // whose second-level medians are simply not used.  Round 2's first geometry (32x32 px, runs of four, the 272-px halo ring done in
 // pixel pairs by half of the waves) issued 5.3 network operations per wave and output pixel; this one 4.5.
 #ifndef MED_BTY
-#define MED_BTY 28
+#define MED_BTY 28                               // (60: 64x64 region, 512 threads, two workgroups per CU -- measured 5 % slower)
 #endif
 constexpr int BTX = 60, BTY = MED_BTY;           // output tile
 constexpr int RX = BTX + 4, RY = BTY + 4;        // first-level region
@@ -437,8 +437,9 @@ DEVI float vmed3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %
 #define MD3(a, b, c) vmed3(a, b, c)
 // The medians of eight horizontally adjacent pixels from one 5x12 window: columns sorted by med3 insertion, neighbouring columns merged
 // pairwise and shared by up to four windows, of a pixel pair's 20 common samples only the six ranks that a fifth column can still turn
-// into the median (tools/gen_median_run.py builds the network and verifies every window on all 2^25 binary inputs): 468 operations,
-// 58.5 per median, against 98 for the classic 99-exchange network with shared triples.
+// into the median, five nested med3 finish a window; the graph is then re-synthesised with three-input cells (tools/gen_median_run.py
+// builds it, picks the cheapest cover and verifies every window of the result on all 2^25 binary inputs): 375 operations, 46.9 per
+// median, against 98 for the classic 99-exchange network with shared triples (round 1).
 // The window is loaded in pieces: the include calls MED_NEED(c) before the first use of column c (order 1 2 3 4 0 5 ... 11), and
 // need(c, w) fetches the piece that starts there, so the last columns are not held in registers while the first medians are computed.
 template <class Need>
