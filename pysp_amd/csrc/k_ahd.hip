@@ -594,9 +594,9 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     // ---- second level on the same run: g' = (med5(g-r') + med5(g-b') + r' + b') / 2, colour tail, store
     const int qlo = ox == 0 ? 2 : 0;                              // pixels [qlo, qhi) of the run belong to this tile and to the image
     const int qhi = min(ox == RX - 8 ? 6 : 8, W - x0);
-    if (oy < 2 || oy >= RY - 2 || y >= H || qhi <= qlo) return;
+    const bool second = oy >= 2 && oy < RY - 2 && y < H && qhi > qlo;           // no early return: the staged tail below has barriers
     float ma[8], mb[8];
-    {
+    if (second) {
         auto piece = [&](const float* plane) {                     // window starts 8 bytes past a 16-byte boundary: columns 0-1, 2-5, then pairs
             return [=](int c, float w[5][12]) {
                 if (c != 1 && c != 2 && !(c >= 6 && !(c & 1))) return;
@@ -617,6 +617,45 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
         median25_run8(piece(s_d1), ma);
         median25_run8(piece(s_d2), mb);
     }
+    // With a colour tail the pre-tail pixels go through an LDS image of the tile (over the planes, which are dead by now) and are picked up
+    // again four at a time by consecutive threads: the tail then runs on 28 wave-passes of 4 px per tile instead of 32 of 8 runs that carry
+    // idle rows and halo pixels, and the result leaves as three 16-byte stores per thread on consecutive addresses.
+    if (p.tail != 0 && p.vec) {
+        constexpr int SROW = BTX * 3;                             // floats per staged row (720 bytes: 16-byte aligned rows)
+        float* const stage = &lds[0][0][0];
+        static_assert(BTY * SROW <= 3 * B4Y * B4X, "the staged tile fits over the planes");
+        __syncthreads();                                          // every thread is done with the difference planes
+        if (second) {
+            float o[24];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { o[3 * q] = keep_r[q]; o[3 * q + 1] = (((ma[q] + mb[q]) + keep_r[q]) + keep_b[q]) / 2.0f; o[3 * q + 2] = keep_b[q]; }
+            float* sp = stage + (oy - 2) * SROW + (ox - 2) * 3;   // 8-byte aligned; floats [3 qlo, 3 qhi) of the run are this tile's
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (2 * k >= 3 * qlo && 2 * k < 3 * qhi) *reinterpret_cast<float2*>(sp + 2 * k) = make_float2(o[2 * k], o[2 * k + 1]);
+        }
+        __syncthreads();
+        constexpr int GPR = BTX / 4, NGRP = GPR * BTY;
+        char* const tile = reinterpret_cast<char*>(p.out + ((size_t)ty0 * W + tx0) * 3);
+#pragma unroll
+        for (int k = 0; k < (NGRP + NT_B - 1) / NT_B; k++) {
+            const int gi = tid + k * NT_B;
+            const int row = gi / GPR, c = gi - row * GPR;
+            if (gi < NGRP && ty0 + row < H && tx0 + 4 * c < W) {
+                const float4* sp = reinterpret_cast<const float4*>(stage + row * SROW + 12 * c);
+                const float4 v0 = sp[0], v1 = sp[1], v2 = sp[2];
+                float px[4][3] = {{v0.x, v0.y, v0.z}, {v0.w, v1.x, v1.y}, {v1.z, v1.w, v2.x}, {v2.y, v2.z, v2.w}};
+#pragma unroll
+                for (int i = 0; i < 4; i++) colour_tail(p.tail, p.ccm.m, px[i][0], px[i][1], px[i][2]);
+                float4* dp = reinterpret_cast<float4*>(tile + (mul24((unsigned)row, rowbytes) + 48u * (unsigned)c));
+                dp[0] = make_float4(px[0][0], px[0][1], px[0][2], px[1][0]);
+                dp[1] = make_float4(px[1][1], px[1][2], px[2][0], px[2][1]);
+                dp[2] = make_float4(px[2][2], px[3][0], px[3][1], px[3][2]);
+            }
+        }
+        return;
+    }
+    if (!second) return;
     // (row oy >= 2 here: the offset from the origin of region row 2, column 0 is non-negative; the two halo pixels left of the image's
     // first column are addressed but never stored)
     float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out + ((size_t)ty0 * W + (tx0 - 2)) * 3) + (mul24((unsigned)(oy - 2), rowbytes) + 12u * (unsigned)ox));
