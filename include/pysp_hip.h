@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - images are row-major; float32 unless the name says otherwise; H and W are the mosaic
- *     dimensions and must be even (2x2 CFA, RGGB order: R=(0,0) G1=(0,1) G2=(1,0) B=(1,1));
+ *     dimensions and must be even, at most 2^20 per side (2x2 CFA, RGGB order: R=(0,0) G1=(0,1) G2=(1,0) B=(1,1));
+ *     WarpRectilinear images at most 2^17 = 131072 per side (cv2.remap itself stops at 32767);
  *   - entry points return 0 on success and a negative PYSP_E* code on failure;
  *     pysp_last_error() returns a thread-local description of the last failure;
  *   - "host" entry points borrow caller memory for the duration of the call (outputs are written

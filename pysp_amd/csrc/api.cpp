@@ -43,7 +43,8 @@ int fail(int code, const char* fmt, ...) {
         if (_r != 0) return fail(PYSP_EHIP, "%s: %s", #expr, hipGetErrorString(hipGetLastError())); \
     } while (0)
 
-bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1); }
+// even, >= 2 and <= 2^20 per side: the kernels form tile-local byte offsets with 24-bit multiplies (row * W * 12 bytes), and no sensor is near that
+bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && H <= (1 << 20) && W <= (1 << 20); }
 
 }  // namespace
 
@@ -912,6 +913,7 @@ int pysp_warp_rectilinear_rows_dev(pysp_ctx* ctx, const float* d_in, float* d_ou
     if (!d_in || !d_out || !coeffs || d_in == d_out) return fail(PYSP_EBADARG, "warp_rectilinear: null or aliased buffers");
     if (planes != 3 || H < 1 || W < 1) return fail(PYSP_EBADARG, "warp_rectilinear: plane count %d does not match a 3-channel image", planes);
     if (row0 < 0 || row1 > H || row0 >= row1) return fail(PYSP_EBADARG, "warp_rectilinear: rows [%d,%d) are not inside the %d-row frame", row0, row1, H);
+    if (H > (1 << 17) || W > (1 << 17)) return fail(PYSP_EBADARG, "warp_rectilinear: %dx%d is beyond 131072 px per side", H, W);
     ctx->tic();
     ctx->tl.begin(ctx->stream, "k_warp_remap");
     LAUNCH_TRY(launch_warp_remap(ctx->stream, d_in, d_out, H, W, coeffs, planes, cx_norm, cy_norm, scale, ctx->lanczos, row0, row1));

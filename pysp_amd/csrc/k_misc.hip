@@ -256,10 +256,13 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     const int by0 = p.row0 + tby * WBY;
     const int x = tbx * WBX + (tid & 63), y0 = by0 + (tid >> 6) * WRPT;
     const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
+    // np.clip (chan_distortion_corr.py:95-96) as one v_med3 (the same value for every coordinate but NaN, which both forms turn into cell 0), and
+    // cv2.remap's round(32 v) without v_rndne + v_cvt: 32 v is exact and < 2^22 (sides <= 2^17, checked by the caller), so 32 v + 1.5 * 2^23 has
+    // the half-even rounded integer in its low mantissa bits.  Cell and phase are bit fields of that word minus the constant.
     auto cell = [&](float mx, float my, int& fx, int& fy) {
-        mx = mx < 0.0f ? 0.0f : (mx > xmax ? xmax : mx);       // np.clip, chan_distortion_corr.py:95-96
-        my = my < 0.0f ? 0.0f : (my > ymax ? ymax : my);
-        fx = (int)rintf(mx * 32.0f); fy = (int)rintf(my * 32.0f);
+        mx = __builtin_amdgcn_fmed3f(mx, 0.0f, xmax); my = __builtin_amdgcn_fmed3f(my, 0.0f, ymax);
+        fx = __float_as_int(__builtin_fmaf(mx, 32.0f, 12582912.0f)) - 0x4B400000;
+        fy = __float_as_int(__builtin_fmaf(my, 32.0f, 12582912.0f)) - 0x4B400000;
     };
     if (tid < 12) {
         const int c = tid >> 2, k = tid & 3;
@@ -284,23 +287,35 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     int tx0[3], ty0[3], tw[3], th[3];
     constexpr int NLD = (WTW * WTH + 255) / 256;     // tile cells per thread and channel
     float stage[3][NLD];
+    // cell k of this thread on the fixed WTW grid, and its byte offset from the rectangle's origin: the same for the three channels
+    int cry[NLD], crx[NLD];
+    unsigned coff[NLD];
+    const unsigned rowbytes = (unsigned)p.W * 12u;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int idx = tid + k * 256;
+        cry[k] = idx / WTW; crx[k] = idx - cry[k] * WTW;
+        coff[k] = mul24((unsigned)cry[k], rowbytes) + 12u * (unsigned)crx[k];
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         int lox = min(min(corner[c][0][0], corner[c][1][0]), min(corner[c][2][0], corner[c][3][0]));
         int loy = min(min(corner[c][0][1], corner[c][1][1]), min(corner[c][2][1], corner[c][3][1]));
         int hix = max(max(corner[c][0][0], corner[c][1][0]), max(corner[c][2][0], corner[c][3][0]));
         int hiy = max(max(corner[c][0][1], corner[c][1][1]), max(corner[c][2][1], corner[c][3][1]));
-        tx0[c] = lox - 3 - 2; ty0[c] = loy - 3 - 2;            // 2 cells of margin on every side
-        tw[c] = min(hix + 4 + 2 - tx0[c] + 1, WTW); th[c] = min(hiy + 4 + 2 - ty0[c] + 1, WTH);
-        // all loads of the three tiles are issued before the first LDS store (cells are addressed on the fixed WTW grid:
-        // constant divisions, and every cell of the buffer gets a value -- zero outside the image or the rectangle)
+        // the rectangle is the same for the whole workgroup: kept in scalar registers
+        tx0[c] = __builtin_amdgcn_readfirstlane(lox - 3 - 2); ty0[c] = __builtin_amdgcn_readfirstlane(loy - 3 - 2);            // 2 cells of margin on every side
+        tw[c] = __builtin_amdgcn_readfirstlane(min(hix + 4 + 2 - tx0[c] + 1, WTW)); th[c] = __builtin_amdgcn_readfirstlane(min(hiy + 4 + 2 - ty0[c] + 1, WTH));
+        // all loads of the three tiles are issued before the first LDS store; every cell of the buffer gets a value -- zero outside the
+        // image or the rectangle.  A cell is inside both iff its row is in [ylo, ylo + yn) and its column in [xlo, xlo + xn): two
+        // subtract-and-compare pairs; the load takes (scalar rectangle origin, 32-bit cell offset).
+        const char* const org = reinterpret_cast<const char*>(p.in + ((long long)ty0[c] * p.W + tx0[c]) * 3 + c);   // may lie outside the image: never read there
+        const int ylo = max(0, -ty0[c]), yn = max(0, min(th[c], p.H - ty0[c]) - ylo);
+        const int xlo = max(0, -tx0[c]), xn = max(0, min(tw[c], p.W - tx0[c]) - xlo);
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
-            int idx = tid + k * 256;
-            int ry = idx / WTW, rx = idx - ry * WTW;
-            int gx = tx0[c] + rx, gy = ty0[c] + ry;
-            bool ok = ry < th[c] && rx < tw[c] && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            stage[c][k] = ok ? p.in[((size_t)gy * p.W + gx) * 3 + c] : 0.0f;
+            const bool ok = (unsigned)(cry[k] - ylo) < (unsigned)yn && (unsigned)(crx[k] - xlo) < (unsigned)xn;
+            stage[c][k] = ok ? *reinterpret_cast<const float*>(org + coff[k]) : 0.0f;
         }
     }
 #pragma unroll
