@@ -13,25 +13,37 @@ struct MosaicSrc {
     const float* f32;
     const uint16_t* u16;
     float black[4], sat[4];
+    double rsat[4];            // 1 / sat, correctly rounded to float64 on the host
 };
+// v / sat, the float32 division of bayer_normalize, without the ten-instruction IEEE sequence: float(double(v) * RN53(1 / sat)) IS the correctly
+// rounded float32 quotient.  The product carries a relative error <= 2^-52; a quotient of two float32 numbers that is not itself a float32 lies
+// at least 2^-49 (relative) away from every rounding boundary of the float32 grid (the boundary has a 25-bit odd significand M, and
+// v - sat * M * 2^k is a non-zero multiple of the grid of a 49-bit product), and an exactly representable quotient is reproduced.
+DEVI float div_by_sat(float v, double rsat) { return (float)((double)v * rsat); }
 template <bool U16>
 DEVI float load_mosaic(const MosaicSrc& m, size_t idx, int site) {
     if (U16) {
         float v = (float)m.u16[idx] - m.black[site];
         v = v < 0.0f ? 0.0f : (v > m.sat[site] ? m.sat[site] : v);
-        return v / m.sat[site];
+        return div_by_sat(v, m.rsat[site]);
     }
     return m.f32[idx];
 }
-// Two horizontally adjacent mosaic samples (even column first) as one 8-byte (f32) / 4-byte (u16) load.
+// Two horizontally adjacent mosaic samples (even column first) as one 8-byte (f32) / 4-byte (u16) load.  odd_row selects the CFA sites:
+// even row (R, G1) = levels 0, 1; odd row (G2, B) = levels 3, 2 (rawpy's R G B G order).  The levels are picked with selects between
+// scalar registers -- indexing the kernel-argument arrays with a per-lane index makes the compiler read them from memory, per lane,
+// with a wait after each (that cost the uint16 path 14 % of the select kernel when a third array joined the two).
 template <bool U16>
-DEVI float2 load_mosaic_pair(const MosaicSrc& m, size_t idx, int site_even, int site_odd) {
+DEVI float2 load_mosaic_pair(const MosaicSrc& m, size_t idx, bool odd_row) {
     if (U16) {
+        const float be = odd_row ? m.black[3] : m.black[0], bo = odd_row ? m.black[2] : m.black[1];
+        const float se = odd_row ? m.sat[3] : m.sat[0], so = odd_row ? m.sat[2] : m.sat[1];
+        const double re = odd_row ? m.rsat[3] : m.rsat[0], ro = odd_row ? m.rsat[2] : m.rsat[1];
         ushort2 raw = *reinterpret_cast<const ushort2*>(m.u16 + idx);
-        float a = (float)raw.x - m.black[site_even], b = (float)raw.y - m.black[site_odd];
-        a = a < 0.0f ? 0.0f : (a > m.sat[site_even] ? m.sat[site_even] : a);
-        b = b < 0.0f ? 0.0f : (b > m.sat[site_odd] ? m.sat[site_odd] : b);
-        return make_float2(a / m.sat[site_even], b / m.sat[site_odd]);
+        float a = (float)raw.x - be, b = (float)raw.y - bo;
+        a = a < 0.0f ? 0.0f : (a > se ? se : a);
+        b = b < 0.0f ? 0.0f : (b > so ? so : b);
+        return make_float2(div_by_sat(a, re), div_by_sat(b, ro));
     }
     return *reinterpret_cast<const float2*>(m.f32 + idx);
 }

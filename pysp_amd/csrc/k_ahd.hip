@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
                 tmp[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.src.f32 + (size_t)(2 * (tq0y - 3)) * W + 2 * (tq0x - 3)) +
                                                           (mul24((unsigned)ry, (unsigned)W * 4u) + 8u * (unsigned)mx));
             else
-                tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy ? 3 : 0, dy ? 2 : 1);
+                tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy != 0);
         }
 #pragma unroll
         for (int k = 0; k < NL; k++) {

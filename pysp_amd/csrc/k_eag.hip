@@ -65,8 +65,8 @@ DEVI void mosaic_prefetch(const MosaicSrc& src, float4 tmp[NL4], int tid, int W,
                 qj0 = TINY ? b_sym(qj0, w) : b_sym1(qj0, w);
                 qj1 = TINY ? b_sym(qj1, w) : b_sym1(qj1, w);
             }
-            float2 lo = load_mosaic_pair<U16>(src, (size_t)(2 * qi + dy) * W + 2 * qj0, dy ? 3 : 0, dy ? 2 : 1);
-            float2 hi = load_mosaic_pair<U16>(src, (size_t)(2 * qi + dy) * W + 2 * qj1, dy ? 3 : 0, dy ? 2 : 1);
+            float2 lo = load_mosaic_pair<U16>(src, (size_t)(2 * qi + dy) * W + 2 * qj0, dy != 0);
+            float2 hi = load_mosaic_pair<U16>(src, (size_t)(2 * qi + dy) * W + 2 * qj1, dy != 0);
             tmp[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
     }
@@ -438,12 +438,12 @@ int launch_ca_green(hipStream_t st, const float* bayer, int H, int W, float* out
 MosaicSrc mosaic_f32(const float* d_bayer) {
     MosaicSrc m;
     m.f32 = d_bayer; m.u16 = nullptr;
-    for (int i = 0; i < 4; i++) { m.black[i] = 0.0f; m.sat[i] = 1.0f; }
+    for (int i = 0; i < 4; i++) { m.black[i] = 0.0f; m.sat[i] = 1.0f; m.rsat[i] = 1.0; }
     return m;
 }
 MosaicSrc mosaic_u16(const uint16_t* d_bayer, const float black[4], const float sat[4]) {
     MosaicSrc m;
     m.f32 = nullptr; m.u16 = d_bayer;
-    for (int i = 0; i < 4; i++) { m.black[i] = black[i]; m.sat[i] = sat[i]; }
+    for (int i = 0; i < 4; i++) { m.black[i] = black[i]; m.sat[i] = sat[i]; m.rsat[i] = 1.0 / (double)sat[i]; }
     return m;
 }
