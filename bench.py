@@ -46,6 +46,7 @@ WORKLOADS = {
     # name: (H, W, quality, stages, description[, tail])   tail: 2 = to_lin_srgb + lin_srgb_to_srgb (default), 1 = to_lin_srgb only
     "ahd24": (4000, 6000, 2, 1, "24MP RGGB, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb"),
     "ahd24u16": (4000, 6000, 2, 1, "24MP RGGB uint16 sensor mosaic, bayer_normalize fused into the tile loader + AHD (postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb (14 B/px)"),
+    "eag24ccmu16": (4000, 6000, 1, 0, "24MP RGGB uint16 sensor mosaic, bayer_normalize fused into the tile loader + EAG + WB + 3x3 CCM (14 B/px)", 1),
     "eag24": (4000, 6000, 1, 0, "24MP RGGB, QualityDemosaic.Fast (EAG) + to_lin_srgb + lin_srgb_to_srgb"),
     "draft12": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + to_lin_srgb + lin_srgb_to_srgb"),
     "draft12ccm": (3000, 4000, 0, 0, "12MP RGGB, QualityDemosaic.Draft + WB + 3x3 CCM (to_lin_srgb)", 1),

@@ -33,17 +33,21 @@ DEVI float load_mosaic(const MosaicSrc& m, size_t idx, int site) {
 // even row (R, G1) = levels 0, 1; odd row (G2, B) = levels 3, 2 (rawpy's R G B G order).  The levels are picked with selects between
 // scalar registers -- indexing the kernel-argument arrays with a per-lane index makes the compiler read them from memory, per lane,
 // with a wait after each (that cost the uint16 path 14 % of the select kernel when a third array joined the two).
+// bayer_normalize (image.py:229) of one raw sample pair: (raw - black) clipped to [0, sat], / sat
+DEVI float2 normalize_pair(const MosaicSrc& m, unsigned short rx, unsigned short ry, bool odd_row) {
+    const float be = odd_row ? m.black[3] : m.black[0], bo = odd_row ? m.black[2] : m.black[1];
+    const float se = odd_row ? m.sat[3] : m.sat[0], so = odd_row ? m.sat[2] : m.sat[1];
+    const double re = odd_row ? m.rsat[3] : m.rsat[0], ro = odd_row ? m.rsat[2] : m.rsat[1];
+    float a = (float)rx - be, b = (float)ry - bo;
+    a = a < 0.0f ? 0.0f : (a > se ? se : a);
+    b = b < 0.0f ? 0.0f : (b > so ? so : b);
+    return make_float2(div_by_sat(a, re), div_by_sat(b, ro));
+}
 template <bool U16>
 DEVI float2 load_mosaic_pair(const MosaicSrc& m, size_t idx, bool odd_row) {
     if (U16) {
-        const float be = odd_row ? m.black[3] : m.black[0], bo = odd_row ? m.black[2] : m.black[1];
-        const float se = odd_row ? m.sat[3] : m.sat[0], so = odd_row ? m.sat[2] : m.sat[1];
-        const double re = odd_row ? m.rsat[3] : m.rsat[0], ro = odd_row ? m.rsat[2] : m.rsat[1];
-        ushort2 raw = *reinterpret_cast<const ushort2*>(m.u16 + idx);
-        float a = (float)raw.x - be, b = (float)raw.y - bo;
-        a = a < 0.0f ? 0.0f : (a > se ? se : a);
-        b = b < 0.0f ? 0.0f : (b > so ? so : b);
-        return make_float2(div_by_sat(a, re), div_by_sat(b, ro));
+        const ushort2 raw = *reinterpret_cast<const ushort2*>(m.u16 + idx);
+        return normalize_pair(m, raw.x, raw.y, odd_row);
     }
     return *reinterpret_cast<const float2*>(m.f32 + idx);
 }
