@@ -63,8 +63,7 @@ def merge(g, A, B, W):
 
 def sel(g, S, T):
     """median of 25 = 6th smallest of S[0..5] (ranks 8..13 of the shared 20, sorted) + T[0..4] (the fifth column, sorted): five nested
-    clamps (found by exhaustive search over formulas on sorted operands, tools/scratch is not needed to check it: the 0-1 verification
-    below covers it);  the min/max form min(s13, max(s12,t1), ..., max(s8,t5)) takes eight operations"""
+    clamps (found by tools/formula_dp.py 6 5 6; the 0-1 verification below covers it);  the min/max form min(s13, max(s12,t1), ..., max(s8,t5)) takes eight operations"""
     m = g.op('med3', S[4], T[0], T[4])
     m = g.op('med3', S[3], T[1], m)
     m = g.op('med3', S[2], T[2], m)
