@@ -88,6 +88,21 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def ulp_compare(np, got, ref):
+    """(number of values whose bits differ, largest distance in float32 ULPs) between two float32 arrays; NaN == NaN, +0 == -0."""
+    a = np.ascontiguousarray(got, dtype=np.float32).reshape(-1)
+    b = np.ascontiguousarray(ref, dtype=np.float32).reshape(-1)
+    n_bad, worst = 0, 0
+    for s0 in range(0, a.size, 1 << 24):                    # in pieces: the int64 temporaries of a whole 24 MP frame are 1.7 GB
+        x, y = a[s0:s0 + (1 << 24)], b[s0:s0 + (1 << 24)]
+        ne = (x.view(np.int32) != y.view(np.int32)) & ~(np.isnan(x) & np.isnan(y)) & ~((x == 0) & (y == 0))
+        if ne.any():
+            xi, yi = x[ne].view(np.int32).astype(np.int64), y[ne].view(np.int32).astype(np.int64)
+            xi = np.where(xi < 0, -(xi & 0x7FFFFFFF), xi); yi = np.where(yi < 0, -(yi & 0x7FFFFFFF), yi)
+            n_bad += int(ne.sum()); worst = max(worst, int(np.abs(xi - yi).max()))
+    return n_bad, worst
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: become the launcher's parent.  Nothing in this process has touched the GPU."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -403,33 +418,67 @@ def main() -> None:
                             "spread over the chip's 1024 SIMDs at 2.4 GHz against the 2-cycle issue rate of a wave64 instruction: the AHD kernels are bound by VALU issue, not by HBM"}
 
     cpu_baseline = None
+    verify = None
     if world == 1 and not args.no_cpu_baseline and quality >= 0 and args.workload != "cfg5":
         try:
             from oracle import oracle
             Mo = p[3:].reshape(3, 3)
+            wbo = p[:3].astype(np.float32)
+            u16 = args.workload.endswith("u16")
             done, dt = 0, 0.0
-            for f in frames:                         # bounded sample: whole resident frames until about 10 s of CPU work are spent
+            ver = {"frames": 0, "max_ulp": 0, "values": 0, "nonzero_ulp": 0}
+            if args.workload == "cfg3":              # one batch call fills outs[0..nf-1]
+                step(0)
+                fence()
+            for fi, f in enumerate(frames):          # bounded sample: whole resident frames until about 10 s of CPU work are spent
                 sample = np.ascontiguousarray(f.cpu().numpy())
-                if sample.dtype != np.float32:
+                if u16:
                     sample = oracle.bayer_normalize(sample.view(np.uint16), [512.0] * 4, [15871.0] * 4)
                 t1 = time.perf_counter()
                 if tail == 2:
-                    oracle.pipeline_srgb(sample, p[:3].astype(np.float32), Mo, quality, False, stages, False)
+                    ref = oracle.pipeline_srgb(sample, wbo, Mo, quality, False, stages, False)
                 else:
                     if quality < 2:
-                        raw = [oracle.demosaic_draft, oracle.demosaic_eag][quality](sample, p[:3].astype(np.float32))
+                        ref = [oracle.demosaic_draft, oracle.demosaic_eag][quality](sample, wbo)
                     else:
-                        raw = oracle.demosaic_ahd(sample, p[:3].astype(np.float32), Mo, False, stages)
+                        ref = oracle.demosaic_ahd(sample, wbo, Mo, False, stages)
                     if tail == 1:
-                        oracle.cam_to_rgb(raw, Mo, True)
+                        ref = oracle.cam_to_rgb(ref, Mo, True)
                 dt += time.perf_counter() - t1
                 done += 1
+                # ---- verify: the very call of the timed region (same entry point, same whole-frame launch, same frame, same output
+                # buffer) once more, downloaded and compared with the oracle's result for that frame, value by value
+                if True:
+                    if args.workload != "cfg3":
+                        step(fi)
+                        fence()
+                    got = (outs[fi] if args.workload == "cfg3" else outs[fi % n_streams]).cpu().numpy()
+                    n_bad, worst = ulp_compare(np, got, ref)
+                    ver["frames"] += 1; ver["values"] += got.size; ver["nonzero_ulp"] += n_bad; ver["max_ulp"] = max(ver["max_ulp"], worst)
+                    del got
+                del ref
                 if dt > 10.0:
                     break
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
             cpu_baseline = {"value": round(done * H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": oracle.threads(), "kind": "port",
-                            "sample": f"{done} whole frame(s) of the benchmark ({H}x{W}), {dt:.1f} s, oracle/pysp_oracle.c, OpenMP, same path"}
+                            "cores_available": os.cpu_count(), "cores_in_affinity_mask": avail, "threads_used": oracle.threads(), "thread_cap": oracle.thread_cap_reason(),
+                            "sample": f"{done} whole frame(s) of the benchmark ({H}x{W}), {dt:.1f} s, oracle/pysp_oracle.c, OpenMP team of {oracle.threads()} "
+                                      f"({oracle.thread_cap_reason()}; os.cpu_count() = {os.cpu_count()}), same path"}
+            if ver["frames"]:
+                verify = {"frames": ver["frames"], "max_ulp": int(ver["max_ulp"]), "frac_nonzero_ulp": ver["nonzero_ulp"] / ver["values"],
+                          "values_compared": ver["values"], "bit_exact": ver["nonzero_ulp"] == 0,
+                          "what": "GPU output of the timed call (same entry point and whole-frame launch, H x W x 3 float32) vs oracle/pysp_oracle.c on the same frame(s)"}
+                if quality == 2 and tail != 0 and not u16:
+                    # the demosaic alone (RawDemosaicData.image: select kernel + median stages, no colour tail) of frame 0, bit for bit
+                    raw_ref = oracle.demosaic_ahd(np.ascontiguousarray(frames[0].cpu().numpy()), wbo, Mo, False, stages)
+                    _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(frames[0].data_ptr()), H, W, state["wb"], state["M"], quality, 0, stages, 0,
+                                                   ctypes.c_void_p(outs[0].data_ptr())))
+                    fence()
+                    nb, _w = ulp_compare(np, outs[0].cpu().numpy(), raw_ref)
+                    verify["bit_exact_demosaic"] = nb == 0
+                    del raw_ref
         except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
-            cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc}"}
+            cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc!r}"}
 
     cfg = {"workload": desc, "H": H, "W": W, "lab_mode": args.lab_mode, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
            "backend": ("rccl" if args.backend == "nccl" else "gloo") if dist is not None else None,
@@ -442,13 +491,16 @@ def main() -> None:
         "value": round(value, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "config": cfg,
-        "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "verify": verify,
     }
     if phase_ms is not None:
         line["phases_ms"] = phase_ms
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if verify is not None and verify["max_ulp"] > 1:
+        sys.stderr.write(f"bench.py: GPU output differs from the oracle by {verify['max_ulp']} ULP (> 1) -- parity broken\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -42,15 +42,50 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
 
 
-def threads() -> int:
-    """OpenMP team size used by the oracle: OMP_NUM_THREADS if set, else min(available cores, 16)."""
+def _cgroup_cpu_quota() -> Optional[float]:
+    """CPUs this process may use per the cgroup's CPU bandwidth limit (v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
+_DEFAULT_CAP = 16   # a 1-GPU box of the pool is a 16-CPU share of a 256-CPU host (the cores are visible, the share is what may be used)
+
+
+def _team():
+    """(OpenMP team size, why): OMP_NUM_THREADS if set; else the cgroup CPU quota if there is one; else min(cores in the affinity mask, 16)."""
     if os.environ.get("OMP_NUM_THREADS", "").isdigit():
-        return max(1, int(os.environ["OMP_NUM_THREADS"]))
+        return max(1, int(os.environ["OMP_NUM_THREADS"])), "OMP_NUM_THREADS"
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+    q = _cgroup_cpu_quota()
+    if q is not None:
+        return max(1, min(n, int(q + 0.999))), f"cgroup CPU quota {q:g}"
+    if n > _DEFAULT_CAP:
+        return _DEFAULT_CAP, f"capped at the box's 16-CPU share per GPU ({n} cores visible, no cgroup quota readable; OMP_NUM_THREADS overrides)"
+    return max(1, n), "all cores of the affinity mask"
+
+
+def threads() -> int:
+    """OpenMP team size used by the oracle (see _team)."""
+    return _team()[0]
+
+
+def thread_cap_reason() -> str:
+    return _team()[1]
 
 
 def lib() -> ctypes.CDLL:

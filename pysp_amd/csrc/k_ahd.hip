@@ -168,7 +168,8 @@ struct AhdParams {
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
 // HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs
 // registers: 100 VGPRs (4 waves per SIMD) with it compiled in, 92 (5 waves) without -- the non-HDR kernel stays at 92.
-template <bool TINY, bool U16, bool HDR, int LAB>
+// TAIL: a colour tail may follow the selection (only when no median stage does); the instance without it is the benchmark's.
+template <bool TINY, bool U16, bool HDR, int LAB, bool TAIL>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
     // LDS, 30.6 KB per workgroup (five workgroups per CU).  The mosaic planes are dead once P1 and the green reads below are
     // done, and the horizontal g/D planes once the horizontal P2 is: the Lab buffer of both directions lies over them (a barrier
@@ -181,6 +182,10 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     float* const lab = planes;                       // [3][LPR][LPS], one direction at a time
     float* const gq0 = planes + 4 * MWY * MWX;       // horizontal: GHR, GHB, DHR, DHB
     float* const gq1 = planes + NFRONT;              // vertical:   GVR, GVB, DVR, DVB
+#ifdef AHD_LDS_PAD
+    __shared__ float s_pad[AHD_LDS_PAD / 4];                                 // experiment: occupancy probe (LDS-limited workgroups per CU)
+    if (p.H < 0) s_pad[threadIdx.x] = 1.0f;
+#endif
     __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 128];                 // 12 KB of closed-form tables; Lab mode 1 reads its grid from L2 and keeps only the vote map here
     unsigned short* const vmap = reinterpret_cast<unsigned short*>(s_labtab);   // [MPR][MPS] votes: h | v << 8
     static_assert(MPR * MPS * sizeof(unsigned short) <= (((127 + LAB_DEC_LOEXP) << LAB_DEC_NB) & (LAB_DEC_SLOTS - 1)) * sizeof(float4),
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             px[k][0] = rgbh[k][0] * c + rgbv[k][0] * nc;
             px[k][1] = rgbh[k][1] * c + rgbv[k][1] * nc;
             px[k][2] = rgbh[k][2] * c + rgbv[k][2] * nc;
-            colour_tail(p.tail, M, px[k][0], px[k][1], px[k][2]);
+            if (TAIL) colour_tail(p.tail, M, px[k][0], px[k][1], px[k][2]);
         }
         // two rows of three 8-byte stores instead of twelve dword stores; uniform tile origin + tile-local 32-bit offset (inner: lqy, lqx >= 1)
         store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, lqy - 1, lqx - 1, px);
@@ -704,15 +709,17 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
     dim3 ga((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY);
     if (tl) tl->begin(st, "k_ahd_select");
     const bool tiny = H / 2 < 4 || W / 2 < 4, u16 = src.u16 != nullptr;
-#define AHD_LAUNCH(HDRV, LABV) \
+#define AHD_LAUNCH2(HDRV, LABV, TAILV) \
     do { \
-        if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
-        else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
-        else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
-        else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV, LABV>), ga, dim3(NT_A), 0, st, a); \
+        if (tiny && u16) hipLaunchKernelGGL((k_ahd_select<true, true, HDRV, LABV, TAILV>), ga, dim3(NT_A), 0, st, a); \
+        else if (tiny) hipLaunchKernelGGL((k_ahd_select<true, false, HDRV, LABV, TAILV>), ga, dim3(NT_A), 0, st, a); \
+        else if (u16) hipLaunchKernelGGL((k_ahd_select<false, true, HDRV, LABV, TAILV>), ga, dim3(NT_A), 0, st, a); \
+        else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV, LABV, TAILV>), ga, dim3(NT_A), 0, st, a); \
     } while (0)
+#define AHD_LAUNCH(HDRV, LABV) do { if (a.tail != 0) AHD_LAUNCH2(HDRV, LABV, true); else AHD_LAUNCH2(HDRV, LABV, false); } while (0)
     if (d_lablut) { if (hdr) AHD_LAUNCH(true, 1); else AHD_LAUNCH(false, 1); }
     else { if (hdr) AHD_LAUNCH(true, 0); else AHD_LAUNCH(false, 0); }
+#undef AHD_LAUNCH2
 #undef AHD_LAUNCH
     if (tl) tl->end(st);
     const float* cur = a.out;

@@ -234,6 +234,46 @@ def test_full_size_24mp_properties(orc, wbobj):
     assert np.ptp(out) < 1e-6
 
 
+@pytest.mark.gpu
+def test_whole_frame_24mp_device_launch(orc, wbobj):
+    """The benchmark's own launch (missing 4): pysp_pipeline_dev on the WHOLE 4000x6000 frame -- one select grid of
+    215x143 tiles, one median grid -- equals (a) the banded host entry (256-row bands, other grids) bit for bit over the full frame and
+    (b) the oracle on crops that cover tile rows / columns at the top-left, the interior, the bottom-right and the frame's last tiles."""
+    import ctypes
+    from pysp_amd import _lib
+    from pysp_amd.synth import rggb_frame
+    H, W = 4000, 6000
+    bay = rggb_frame(H, W, 1000)
+    wb, M = _wbM(orc)
+    L, ctx = _lib.lib(), _lib.default_context()
+    banded = np.empty((H, W, 3), np.float32)
+    _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 0, 1, 0, _lib.ptr(banded)))
+    for tail, ref in ((2, banded), (0, None)):
+        import torch
+        dctx = _lib.Context(0)
+        t_in = torch.from_numpy(bay).to("cuda:0")
+        t_out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        _lib.check(L.pysp_pipeline_dev(dctx.handle, ctypes.c_void_p(t_in.data_ptr()), H, W, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 0, 1, tail, ctypes.c_void_p(t_out.data_ptr())))
+        dctx.sync()
+        whole = t_out.cpu().numpy()
+        del t_in, t_out
+        if ref is not None:
+            assert np.array_equal(whole, ref)
+        # oracle on crops (margin 16 px inside the crop unless the crop touches the frame edge)
+        for (y0, x0, h, w) in ((0, 0, 200, 260), (1986, 2990, 180, 200), (H - 200, W - 260, 200, 260), (0, W - 200, 150, 200), (H - 150, 0, 150, 200)):
+            crop = np.ascontiguousarray(bay[y0:y0 + h, x0:x0 + w])
+            want = orc.pipeline_srgb(crop, wb, M, 2, False, 1, False) if tail == 2 else orc.demosaic_ahd(crop, wb, M, False, 1)
+            ys = slice(0 if y0 == 0 else 16, h if y0 + h == H else h - 16)
+            xs = slice(0 if x0 == 0 else 16, w if x0 + w == W else w - 16)
+            got = whole[y0:y0 + h, x0:x0 + w][ys, xs]
+            if tail == 0:
+                assert np.array_equal(got, want[ys, xs]), (tail, y0, x0)
+            else:       # the bar of test_full_size_24mp_properties for the stage behind the float64 pow
+                u = ulp_diff(got, want[ys, xs])
+                assert u.max() <= 1 and np.mean(u != 0) < 1e-4, (tail, y0, x0)
+
+
 # ---- HDR raw fusion ---------------------------------------------------------------------------------------------------
 def test_fuse_raw_golden_and_oracle(orc, wbobj):
     from pysp_amd.raw_hdr import fuse_exposures_to_raw
