@@ -196,7 +196,7 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
     bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     hot = [v for k, v in kernels.items() if "k_ahd_select" in k or "k_ahd_median_stage" in k]
-    assert len(hot) == 17                                            # sixteen select variants (tiny / uint16 / HDR metric / Lab restatement) and the median stage
+    assert len(hot) == 33                                            # 32 select variants (tiny / uint16 / HDR metric / Lab restatement / colour tail) and the median stage
     for v in hot:                                                    # five 256-thread workgroups per CU: <= 96 VGPRs and <= 32 KB of LDS each
         assert v["vgpr_count"] <= 96 and v["group_segment_fixed_size"] <= 32768, v
 
