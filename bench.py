@@ -218,8 +218,10 @@ def main() -> None:
         extra_cfg = {"bands": world, "band_rows": plan.y1 - plan.y0, "halo_rows": plan.y0 - plan.r0 if rank else plan.r1 - plan.y1,
                      "exchange": args.exchange, "collective": "RCCL all_gather of row bounds + batched send/recv of the needed rows" if not via_host else "gloo, host staged (rehearsal)"}
 
+        xstats: dict = {}
+
         def step(i: int, mark=None) -> None:
-            demosaic_warp_banded_dev(pipe, sub, plan, state["wb_np"], state["M_np"], coeffs, (0.5, 0.5), 1.0, None, args.exchange, via_host, full, outb, mark)
+            demosaic_warp_banded_dev(pipe, sub, plan, state["wb_np"], state["M_np"], coeffs, (0.5, 0.5), 1.0, None, args.exchange, via_host, full, outb, mark, xstats)
     elif quality >= 0:
         # ---- inputs resident in HBM: frame i of rank r uses seed 1000 + r*frames + i
         frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * args.frames + i)).to(dev) for i in range(max(1, args.frames))]
@@ -316,7 +318,23 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if dist is not None:
+        # every rank's own time over the K steps (the reported time is the maximum), and for cfg5 what each rank's row exchange moved
+        mine = [elapsed / args.steps * 1e3]
+        if args.workload == "cfg5":
+            mine += [float(xstats.get("bytes_received", 0)), float(xstats.get("bytes_sent", 0)), float(xstats.get("rows_received", 0))]
+        t = torch.tensor(mine, dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = np.array([e.cpu().numpy() for e in every])
+        rank_ms = {"min": round(float(per_rank[:, 0].min()), 4), "median": round(float(np.median(per_rank[:, 0])), 4), "max": round(float(per_rank[:, 0].max()), 4),
+                   "per_rank": [round(float(v), 4) for v in per_rank[:, 0]]}
+        if args.workload == "cfg5":
+            rank_ms["exchange_bytes_received_per_rank"] = [int(v) for v in per_rank[:, 1]]
+            rank_ms["exchange_bytes_sent_per_rank"] = [int(v) for v in per_rank[:, 2]]
+            rank_ms["exchange_rows_received_per_rank"] = [int(v) for v in per_rank[:, 3]]
+            rank_ms["allgather_bytes_received_per_rank_would_be"] = [int((H - (b1 - b0)) * W * 12) for b0, b1 in plan.bands]
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -388,11 +406,16 @@ def main() -> None:
             px_per_launch = (plan.y1 - plan.y0) * W
         kb = KERNEL_ALG_BYTES_PER_PX.get(dom, alg_bytes_per_px)
         alg_bytes = kb * px_per_launch                            # of the dominant kernel's own launch
-        traffic, valu = None, None
+        traffic, valu, traffic_stale, lib_sha = None, None, None, None
         try:   # HBM bytes and VALU instructions per launch from the PMC passes (rocprofv3 cannot run inside the benchmark itself)
+            import hashlib
+            with open(_lib.LIB_PATH, "rb") as f:
+                lib_sha = hashlib.sha256(f.read()).hexdigest()
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tj = json.load(f).get(args.workload, {})
             traffic = tj.get(dom, {}).get("hbm_bytes")
+            # the counters were collected from a particular build of the library: say so when it is not the one that just ran
+            traffic_stale = any(ent.get("lib_sha256") != lib_sha for k, ent in tj.items() if k in per_kernel) if tj else None
             per = {}
             for k, ent in tj.items():                             # every kernel of the step that has a PMC record
                 if k in per_kernel and ent.get("valu_insts"):
@@ -408,7 +431,11 @@ def main() -> None:
             pass
         achieved = alg_bytes / (per_kernel[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_stale": traffic_stale,
+                    # flat copies of the VALU account of the dominant kernel (the nested object `valu` below carries every kernel)
+                    "valu_insts_per_px": valu["insts_per_px"] if valu else None, "valu_cycles_per_inst": valu["cycles_per_inst"] if valu else None,
+                    "valu_frac_of_2cycle_issue": valu["frac_of_2cycle_issue"] if valu else None,
+                    "step_frac_of_2cycle_issue": valu["step_frac_of_2cycle_issue"] if valu else None, "lib_sha256": lib_sha,
                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(per_kernel[dom], 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
                     "alg_bytes_per_px": kb,
@@ -495,6 +522,8 @@ def main() -> None:
     }
     if phase_ms is not None:
         line["phases_ms"] = phase_ms
+    if rank_ms is not None:
+        line["ranks_ms_per_step"] = rank_ms
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

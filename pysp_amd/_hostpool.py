@@ -6,11 +6,14 @@ page-locked memory (`pysp_host_alloc`).  A block returns to this pool when the l
 collected and is reused by the next result of the same size, so a steady stream of frames settles on a handful of blocks.
 The arrays are ordinary writable float32 ndarrays (`OWNDATA` is False, `.base` is the block).
 
-Limits: at most POOL_FREE_PER_SIZE idle blocks per size are kept and at most PINNED_CAP bytes may be handed out at once;
-beyond that (a caller hoarding results) new results fall back to plain `np.empty`.  PYSP_PINNED_RESULTS=0 disables the pool.
+Limits: at most POOL_FREE_PER_SIZE idle blocks per size and IDLE_CAP idle bytes in all are kept (the least recently released go back to the
+driver first), and handed-out plus idle bytes never exceed PINNED_CAP; beyond that (a caller hoarding results) new results fall back to plain
+`np.empty`.  PYSP_PINNED_RESULTS=0 disables the pool.  The block finalizer can run inside a garbage-collection pass started while this
+module holds its lock (same thread): the lock is re-entrant and the finalizer only queues the block; the queue is drained by the next call.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import threading
@@ -22,24 +25,45 @@ MIN_BYTES = 8 << 20
 POOL_FREE_PER_SIZE = 2
 PINNED_CAP = int(os.environ.get("PYSP_PINNED_CAP", str(6 << 30)))
 _enabled = os.environ.get("PYSP_PINNED_RESULTS", "1") not in ("0", "")
-_lock = threading.Lock()
-_free: dict = {}          # nbytes -> [address, ...]
+IDLE_CAP = int(os.environ.get("PYSP_PINNED_IDLE_CAP", str(2 << 30)))
+_lock = threading.RLock()
+_free: "collections.OrderedDict" = collections.OrderedDict()   # (nbytes, address) -> None, oldest release first
+_idle = 0                 # bytes held idle in _free
 _out = 0                  # bytes currently handed out
+_returned: "collections.deque" = collections.deque()           # (address, nbytes) from finalizers (appending takes no lock)
 
 
 def _release(addr: int, nbytes: int) -> None:
-    global _out
+    """Finalizer of a block: may run at any allocation point of any thread (cyclic GC), so it only queues."""
+    _returned.append((addr, nbytes))
+
+
+def _drain() -> list:
+    """Move finalized blocks into the pool (called with the lock held); returns the addresses that have to go back to the driver."""
+    global _out, _idle
+    drop = []
+    while _returned:
+        addr, n = _returned.popleft()
+        _out -= n
+        if sum(1 for (m, _a) in _free if m == n) < POOL_FREE_PER_SIZE and n <= IDLE_CAP:
+            _free[(n, addr)] = None
+            _idle += n
+        else:
+            drop.append(addr)
+    while _idle > IDLE_CAP and _free:
+        (n, addr), _ = _free.popitem(last=False)                # least recently released first
+        _idle -= n
+        drop.append(addr)
+    return drop
+
+
+def _give_back(addrs) -> None:
     from . import _lib
-    with _lock:
-        _out -= nbytes
-        lst = _free.setdefault(nbytes, [])
-        if len(lst) < POOL_FREE_PER_SIZE:
-            lst.append(addr)
-            return
-    try:
-        _lib.lib().pysp_host_free(ctypes.c_void_p(addr))
-    except Exception:
-        pass
+    for a in addrs:
+        try:
+            _lib.lib().pysp_host_free(ctypes.c_void_p(a))
+        except Exception:
+            pass
 
 
 def empty(shape, dtype=np.float32) -> np.ndarray:
@@ -49,14 +73,20 @@ def empty(shape, dtype=np.float32) -> np.ndarray:
     if not _enabled or n < MIN_BYTES:
         return np.empty(shape, dtype)
     from . import _lib
+    global _idle
     addr = None
     with _lock:
-        if _out + n > PINNED_CAP:
+        drop = _drain()
+        key = next((k for k in reversed(_free) if k[0] == n), None)
+        if key is not None:
+            del _free[key]
+            _idle -= n
+            addr = key[1]
+        elif _out + _idle + n > PINNED_CAP:
+            _give_back(drop)
             return np.empty(shape, dtype)
-        lst = _free.get(n)
-        if lst:
-            addr = lst.pop()
         _out += n
+    _give_back(drop)
     if addr is None:
         addr = _lib.lib().pysp_host_alloc(ctypes.c_size_t(n))
         if not addr:
@@ -70,9 +100,9 @@ def empty(shape, dtype=np.float32) -> np.ndarray:
 
 def trim() -> None:
     """Give every idle block back to the driver."""
-    from . import _lib
+    global _idle
     with _lock:
-        blocks = [a for lst in _free.values() for a in lst]
+        blocks = _drain() + [a for (_n, a) in _free]
         _free.clear()
-    for a in blocks:
-        _lib.lib().pysp_host_free(ctypes.c_void_p(a))
+        _idle = 0
+    _give_back(blocks)

@@ -159,9 +159,12 @@ def check(rc: int) -> None:
 
 
 class Context:
-    """One HIP stream + grow-only device workspace (pysp_ctx).  Not thread-safe: one per thread."""
+    """One HIP stream + grow-only device workspace (pysp_ctx).  The C context is not thread-safe: one per thread for compute calls.
+    `lock` serialises the buffer calls (pysp_dev_alloc / free / upload / download) that lazy arrays make on it -- also from another
+    thread or from the garbage collector.  A context is a handle to a live C object in this process: it cannot be copied or pickled."""
 
     def __init__(self, device: int = 0, stream: int = 0):
+        self.lock = threading.RLock()
         self._h = lib().pysp_ctx_create(int(device), ctypes.c_void_p(stream or None))
         if not self._h:
             raise RuntimeError(f"pysp_ctx_create failed: {last_error()}")
@@ -212,6 +215,15 @@ class Context:
         if getattr(self, "_h", None):
             lib().pysp_ctx_destroy(ctypes.c_void_p(self._h))
             self._h = None
+
+    def __copy__(self):
+        raise TypeError("a pysp Context owns a HIP stream and device memory: it cannot be copied (create a new Context)")
+
+    def __deepcopy__(self, memo):
+        raise TypeError("a pysp Context owns a HIP stream and device memory: it cannot be copied (create a new Context)")
+
+    def __reduce__(self):
+        raise TypeError("a pysp Context cannot be pickled: it is a handle to a live HIP stream of this process")
 
     def __del__(self):
         try:

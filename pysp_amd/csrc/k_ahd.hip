@@ -81,6 +81,30 @@ DEVI void load_lab_win(const float* plane, int lqy, int lqx, bool at_top, bool a
         }
     }
 }
+// The same window in two pieces, so that the fourth row can take the registers of the first once the quad's upper pixel pair has voted:
+// rows [R0, R1) of the window (R0 = 0: rows 0-2 with the top rule; R0 = 3: row 3 with the bottom rule, which copies row 2).
+template <int R0, int R1>
+DEVI void load_lab_rows(const float* plane, int lqy, int lqx, bool at_top, bool at_bot, bool at_left, bool at_right, float w[4][4]) {
+    const float* p = plane + (2 * lqy) * LPS + 2 * lqx;
+#pragma unroll
+    for (int r = R0; r < R1; r++) {
+        float2 a = *reinterpret_cast<const float2*>(p + r * LPS);
+        float2 b = *reinterpret_cast<const float2*>(p + r * LPS + 2);
+        w[r][0] = a.x; w[r][1] = a.y; w[r][2] = b.x; w[r][3] = b.y;
+    }
+    if (at_top | at_bot | at_left | at_right) {   // interior waves skip the selects
+#pragma unroll
+        for (int r = R0; r < R1; r++) {
+            if (at_left) w[r][0] = w[r][1];
+            if (at_right) w[r][3] = w[r][2];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (R0 == 0 && at_top) w[0][c] = w[1][c];
+            if (R1 == 4 && at_bot) w[3][c] = w[2][c];      // row 2 already carries its left / right rule
+        }
+    }
+}
 
 // pyx:22-58 for the four pixels of a quad.  DIR 0: epsilons from the left/right neighbours (map_h),
 // DIR 1: from the up/down neighbours (map_v).  The centre and the two epsilon neighbours always count:
@@ -95,10 +119,10 @@ DEVI int add_lane_bit(int c, unsigned long long m) {
     asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(carry_out) : "v"(c), "s"(m));
     return d;
 }
-template <int DIR>
+template <int DIR, int K0 = 0, int K1 = 4>
 DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = K0; k < K1; k++) {
         const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
         const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
         float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
@@ -127,10 +151,10 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
 // The same vote with nothing taken for granted: all nine cells of each window go through both tests, exactly as
 // pyx:47-58 spells them.  Needed when a Lab value is not finite -- only L can be (HDR mode: L = luma, ahd.py:55,59; a and b
 // come from clipped values) -- because then the comparisons the fast form skips are false (NaN) instead of true.
-template <int DIR>
+template <int DIR, int K0 = 0, int K1 = 4>
 DEVI void vote_quad_literal(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = K0; k < K1; k++) {
         const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
         const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
         float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
@@ -166,30 +190,32 @@ struct AhdParams {
 };
 
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
-// HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs
-// registers: 100 VGPRs (4 waves per SIMD) with it compiled in, 92 (5 waves) without -- the non-HDR kernel stays at 92.
+// HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs registers.
 // TAIL: a colour tail may follow the selection (only when no median stage does); the instance without it is the benchmark's.
+//
+// LDS (round 3 layout, 25.5 KB with the Lab grid of mode 1: SIX workgroups per CU):
+//   mw   [4][MWY][MWX]  white-balanced mosaic planes, alive until the vertical green planes are built; the packed vote map lies over them afterwards
+//   gq   [4][GY][GX]    green at R / B sites and the colour differences of ONE direction at a time (horizontal first, vertical built while the
+//                       horizontal votes run)
+//   lab  [3][LPR][LPS]  Lab of one direction, written by the thread that computes it, straight from its registers (no overlay, no staging barrier)
+// Round 2 laid the Lab buffer over the mosaic and horizontal planes (20.6 KB, five workgroups per CU limited by 92 VGPRs): every thread then had to
+// hold the twelve Lab values of its quad across a barrier, and the eight green samples of its window across both directions.  Measured on MI355X
+// (tools/ab_bench.sh, LDS padding): five -> four workgroups per CU costs this kernel 9 %, four -> three 24 %: it is latency-bound, occupancy is the lever.
 template <bool TINY, bool U16, bool HDR, int LAB, bool TAIL>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
-    // LDS, 30.6 KB per workgroup (five workgroups per CU).  The mosaic planes are dead once P1 and the green reads below are
-    // done, and the horizontal g/D planes once the horizontal P2 is: the Lab buffer of both directions lies over them (a barrier
-    // separates the last read of either from the first Lab write).  The vertical g/D planes follow.  The packed vote map
-    // lives in the first 120 slots of the decode table, which no valid lookup addresses (segments start at slot 128).
-    constexpr int NLAB = 3 * LPR * LPS, NDEAD = 4 * MWY * MWX + 4 * GY * GX, NFRONT = NLAB > NDEAD ? NLAB : NDEAD;
-    static_assert(NFRONT % 4 == 0, "the vertical g/D planes start 16-byte aligned");
-    __shared__ __attribute__((aligned(16))) float planes[NFRONT + 4 * GY * GX];
+    constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GX, NLAB = 3 * LPR * LPS;
+    static_assert(NMW % 4 == 0 && NGQ % 4 == 0, "16-byte aligned sections");
+    __shared__ __attribute__((aligned(16))) float planes[NMW + NGQ + NLAB + 2];     // + 2: the last window row of the last Lab plane is read (never used) one row past LPR
     float* const mw = planes;
-    float* const lab = planes;                       // [3][LPR][LPS], one direction at a time
-    float* const gq0 = planes + 4 * MWY * MWX;       // horizontal: GHR, GHB, DHR, DHB
-    float* const gq1 = planes + NFRONT;              // vertical:   GVR, GVB, DVR, DVB
+    float* const gq = planes + NMW;
+    float* const lab = planes + NMW + NGQ;
+    unsigned short* const vmap = reinterpret_cast<unsigned short*>(planes);      // [MPR][MPS] votes h | v << 8, over the dead mosaic planes
+    static_assert(MPR * MPS * sizeof(unsigned short) <= NMW * sizeof(float), "the vote map fits over the mosaic planes");
 #ifdef AHD_LDS_PAD
     __shared__ float s_pad[AHD_LDS_PAD / 4];                                 // experiment: occupancy probe (LDS-limited workgroups per CU)
     if (p.H < 0) s_pad[threadIdx.x] = 1.0f;
 #endif
-    __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 128];                 // 12 KB of closed-form tables; Lab mode 1 reads its grid from L2 and keeps only the vote map here
-    unsigned short* const vmap = reinterpret_cast<unsigned short*>(s_labtab);   // [MPR][MPS] votes: h | v << 8
-    static_assert(MPR * MPS * sizeof(unsigned short) <= (((127 + LAB_DEC_LOEXP) << LAB_DEC_NB) & (LAB_DEC_SLOTS - 1)) * sizeof(float4),
-                  "the vote map must end before the first used slot of the decode table");
+    __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 1];                    // 12 KB of closed-form tables (Lab mode 0 only; mode 1 reads its grid from L2)
     const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
 
     const int tid = threadIdx.x;
@@ -243,26 +269,31 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     __syncthreads();
 
 #define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
-    // ---- P1: directional green at R/B sites (ahd.py:97-102) and D = sub - g (eag.py:142)
-    for (int idx = tid; idx < GY * GX; idx += NT_A) {
-        int gy = idx / GX, gx = idx - gy * GX;
-        int a = gy + 1, c = gx + 1;
-        if (!inside) {
-            int ri = TINY ? b_101(tq0y - 2 + gy, h) : b_1011(tq0y - 2 + gy, h);   // REFLECT_101 on the quarter plane
-            int rj = TINY ? b_101(tq0x - 2 + gx, w) : b_1011(tq0x - 2 + gx, w);
-            a = ri - (tq0y - 3); c = rj - (tq0x - 3);
-            if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;        // never consumed by a valid output
+    // ---- P1(dir): directional green at R/B sites (ahd.py:97-102) and D = sub - g (eag.py:142) of ONE direction into gq
+    auto green_planes = [&](const int dir) {
+        for (int idx = tid; idx < GY * GX; idx += NT_A) {
+            int gy = idx / GX, gx = idx - gy * GX;
+            int a = gy + 1, c = gx + 1;
+            if (!inside) {
+                int ri = TINY ? b_101(tq0y - 2 + gy, h) : b_1011(tq0y - 2 + gy, h);   // REFLECT_101 on the quarter plane
+                int rj = TINY ? b_101(tq0x - 2 + gx, w) : b_1011(tq0x - 2 + gx, w);
+                a = ri - (tq0y - 3); c = rj - (tq0x - 3);
+                if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;        // never consumed by a valid output
+            }
+            const float rc = MWAT(P_R, a, c), bc = MWAT(P_B, a, c);
+            float gr, gb;
+            if (dir == 0) {
+                gr = (((MWAT(P_R, a, c - 1) * AH0 + MWAT(P_G1, a, c - 1) * AH1) + rc * AH2) + MWAT(P_G1, a, c) * AH1) + MWAT(P_R, a, c + 1) * AH0;
+                gb = (((MWAT(P_B, a, c - 1) * AH0 + MWAT(P_G2, a, c) * AH1) + bc * AH2) + MWAT(P_G2, a, c + 1) * AH1) + MWAT(P_B, a, c + 1) * AH0;
+            } else {
+                gr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
+                gb = (((MWAT(P_B, a - 1, c) * AH0 + MWAT(P_G1, a, c) * AH1) + bc * AH2) + MWAT(P_G1, a + 1, c) * AH1) + MWAT(P_B, a + 1, c) * AH0;
+            }
+            gq[0 * GY * GX + idx] = gr; gq[1 * GY * GX + idx] = gb;
+            gq[2 * GY * GX + idx] = rc - gr; gq[3 * GY * GX + idx] = bc - gb;
         }
-        float rc = MWAT(P_R, a, c), bc = MWAT(P_B, a, c);
-        float ghr = (((MWAT(P_R, a, c - 1) * AH0 + MWAT(P_G1, a, c - 1) * AH1) + rc * AH2) + MWAT(P_G1, a, c) * AH1) + MWAT(P_R, a, c + 1) * AH0;
-        float gvr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
-        float ghb = (((MWAT(P_B, a, c - 1) * AH0 + MWAT(P_G2, a, c) * AH1) + bc * AH2) + MWAT(P_G2, a, c + 1) * AH1) + MWAT(P_B, a, c + 1) * AH0;
-        float gvb = (((MWAT(P_B, a - 1, c) * AH0 + MWAT(P_G1, a, c) * AH1) + bc * AH2) + MWAT(P_G1, a + 1, c) * AH1) + MWAT(P_B, a + 1, c) * AH0;
-        gq0[0 * GY * GX + idx] = ghr; gq1[0 * GY * GX + idx] = gvr;
-        gq0[1 * GY * GX + idx] = ghb; gq1[1 * GY * GX + idx] = gvb;
-        gq0[2 * GY * GX + idx] = rc - ghr; gq1[2 * GY * GX + idx] = rc - gvr;
-        gq0[3 * GY * GX + idx] = bc - ghb; gq1[3 * GY * GX + idx] = bc - gvb;
-    }
+    };
+    green_planes(0);
     __syncthreads();
 
     const int lqy = tid / LQX, lqx = tid - lqy * LQX;
@@ -272,30 +303,26 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
     // vote-map cell of this quad's top-left pixel (map origin = tile origin - 1 px)
     const int vmy = 2 * lqy - 1, vmx = 2 * lqx - 1;
+    const bool inner = active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX;
 
     float rgbh[4][3], rgbv[4][3];   // both candidates stay in registers until the selection
-    const bool inner = active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX;
-    float g1_l = 0, g1_c = 0, g1_dl = 0, g1_d = 0, g2_u = 0, g2_ur = 0, g2_c = 0, g2_r = 0;
-    if (active) {   // green samples of the 4x4 window, shared by both directions
-        g1_l = MWAT(P_G1, my, mx - 1); g1_c = MWAT(P_G1, my, mx); g1_dl = MWAT(P_G1, my + 1, mx - 1); g1_d = MWAT(P_G1, my + 1, mx);
-        g2_u = MWAT(P_G2, my - 1, mx); g2_ur = MWAT(P_G2, my - 1, mx + 1); g2_c = MWAT(P_G2, my, mx); g2_r = MWAT(P_G2, my, mx + 1);
-    }
+    unsigned hvotes = 0;            // the four horizontal counts of the quad (4 bits each) until the vertical ones exist
 
-    // fully unrolled: plane offsets and the vote's direction become constants, and the register allocator does much better
-    // on the two straight-line copies (93 VGPRs) than on the loop (137)
+    // fully unrolled: plane offsets and the vote's direction become constants
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {
-        float labq[4][3], rgbc[4][3];
-        // ---- P2
+        // ---- P2: high-pass of green, photosite-aware resampling of R and B, second white balance + CCM + Lab -> LDS
         if (active) {
-            const float* gqd = dir == 0 ? gq0 : gq1;
-            const float* gR = gqd, *gB = gqd + GY * GX, *dR = gqd + 2 * GY * GX, *dB = gqd + 3 * GY * GX;
+            float (&rgbc)[4][3] = dir == 0 ? rgbh : rgbv;
+            const float* gR = gq, *gB = gq + GY * GX, *dR = gq + 2 * GY * GX, *dB = gq + 3 * GY * GX;
             Win3 wgr = load_win<GX>(gR, gy, gx), wgb = load_win<GX>(gB, gy, gx);
+            // the quad's own two green samples are the same in both candidates: the vertical pass takes them from the horizontal candidate's registers
+            const float g1_c = dir == 0 ? MWAT(P_G1, my, mx) : rgbh[1][1], g2_c = dir == 0 ? MWAT(P_G2, my, mx) : rgbh[2][1];
             // full-resolution green, rows 2qi-1..2qi+2, cols 2qj-1..2qj+2
-            float Wn[4][4] = {{wgb.v[0][0], g2_u, wgb.v[0][1], g2_ur},
-                              {g1_l, wgr.v[1][1], g1_c, wgr.v[1][2]},
-                              {wgb.v[1][0], g2_c, wgb.v[1][1], g2_r},
-                              {g1_dl, wgr.v[2][1], g1_d, wgr.v[2][2]}};
+            float Wn[4][4] = {{wgb.v[0][0], MWAT(P_G2, my - 1, mx), wgb.v[0][1], MWAT(P_G2, my - 1, mx + 1)},
+                              {MWAT(P_G1, my, mx - 1), wgr.v[1][1], g1_c, wgr.v[1][2]},
+                              {wgb.v[1][0], g2_c, wgb.v[1][1], MWAT(P_G2, my, mx + 1)},
+                              {MWAT(P_G1, my + 1, mx - 1), wgr.v[2][1], MWAT(P_G1, my + 1, mx), wgr.v[2][2]}};
             // GaussianBlur border = REFLECT_101 at full resolution: row -1 -> row 1, row H -> row H-2
             if (at_top | at_bot | at_left | at_right) {
 #pragma unroll
@@ -320,53 +347,64 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             { Win3 wd = load_win<GX>(dB, gy, gx); filt_base_br(wd, fd); }
 #pragma unroll
             for (int k = 0; k < 4; k++) bb[k] = fd[k] + (fg[k] + hf[k]);
-            float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
+            const float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
+            // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring); the thread writes its own quad as soon as a pixel is done
+            float* const pl = lab + (2 * lqy + 1) * LPS + 2 * lqx + 1;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                homog_lab<LAB>(lt, p.lablut, rr[k], gg[k], bb[k], p.wb, M, HDR, labq[k][0], labq[k][1], labq[k][2]);
+                float L, A, Bq;
+                homog_lab<LAB>(lt, p.lablut, rr[k], gg[k], bb[k], p.wb, M, HDR, L, A, Bq);
+                float* const o = pl + (k >> 1) * LPS + (k & 1);
+                o[0] = L; o[LPR * LPS] = A; o[2 * LPR * LPS] = Bq;
                 rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
 #ifndef AHD_NO_SB
                 __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
 #endif
             }
         }
-        __syncthreads();   // direction 0: every thread is done with the mosaic and horizontal g/D planes; direction 1: the votes of direction 0 are done with the Lab buffer
-        if (active) {
-            // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float* pl = lab + c * LPR * LPS + (2 * lqy + 1) * LPS + 2 * lqx + 1;
-                pl[0] = labq[0][c]; pl[1] = labq[1][c];
-                pl[LPS] = labq[2][c]; pl[LPS + 1] = labq[3][c];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) { if (dir == 0) rgbh[k][c] = rgbc[k][c]; else rgbv[k][c] = rgbc[k][c]; }
+        __syncthreads();   // Lab of this direction complete; every thread is done with gq
 
-        // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 window
+        // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 Lab window
         if (active) {
+            // the upper pixel pair votes from window rows 0-2, then row 3 arrives (in row 0's registers) for the lower pair: 36 instead of 48 window registers
             float wl[4][4], wa[4][4], wq[4][4];
+            int cnt[4];
+#ifdef AHD_VOTE_WHOLE_WINDOW
             load_lab_win(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_win(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
-            int cnt[4];
             // HDR metric: L = luma (ahd.py:55,59) may be NaN or +-Inf, and then the comparisons the fast form takes for granted
-            // are false; the literal nine-cell form is used throughout (a per-wave switch between the two forms was measured
-            // at 155 VGPRs / 3 waves per SIMD; literal only: see the resource table in DESIGN.md)
+            // are false; the literal nine-cell form is used throughout
             if (HDR) { if (dir == 0) vote_quad_literal<0>(wl, wa, wq, cnt); else vote_quad_literal<1>(wl, wa, wq, cnt); }
             else { if (dir == 0) vote_quad<0>(wl, wa, wq, cnt); else vote_quad<1>(wl, wa, wq, cnt); }
+#else
+            load_lab_rows<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
+            load_lab_rows<0, 3>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
+            load_lab_rows<0, 3>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+            if (HDR) { if (dir == 0) vote_quad_literal<0, 0, 2>(wl, wa, wq, cnt); else vote_quad_literal<1, 0, 2>(wl, wa, wq, cnt); }
+            else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt); else vote_quad<1, 0, 2>(wl, wa, wq, cnt); }
+            __builtin_amdgcn_sched_barrier(0);
+            load_lab_rows<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
+            load_lab_rows<3, 4>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
+            load_lab_rows<3, 4>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+            if (HDR) { if (dir == 0) vote_quad_literal<0, 2, 4>(wl, wa, wq, cnt); else vote_quad_literal<1, 2, 4>(wl, wa, wq, cnt); }
+            else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt); else vote_quad<1, 2, 4>(wl, wa, wq, cnt); }
+#endif
+            if (dir == 0) {
+                hvotes = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
+            } else {
+                // the mosaic planes are dead (the barrier above closed the last P2): the packed map h | v << 8 goes over them
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int yy = vmy + (k >> 1), xx = vmx + (k & 1);
-                if (yy >= 0 && yy < MPR && xx >= 0 && xx < 2 * TQX + 2) {
-                    unsigned short* cell = &vmap[yy * MPS + xx];
-                    if (dir == 0) *cell = (unsigned short)cnt[k];
-                    else *cell = (unsigned short)(*cell | (cnt[k] << 8));
+                for (int k = 0; k < 4; k++) {
+                    int yy = vmy + (k >> 1), xx = vmx + (k & 1);
+                    if (yy >= 0 && yy < MPR && xx >= 0 && xx < 2 * TQX + 2)
+                        vmap[yy * MPS + xx] = (unsigned short)(((hvotes >> (4 * k)) & 15u) | ((unsigned)cnt[k] << 8));
                 }
             }
+        }
+        if (dir == 0) {
+            green_planes(1);   // the vertical planes replace the horizontal ones while the horizontal votes read the Lab buffer
+            __syncthreads();   // ... and the next P2 writes the Lab buffer only after every vote of this direction has read it
         }
     }
 #undef MWAT

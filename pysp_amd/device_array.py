@@ -5,9 +5,14 @@
 reference) costs one upload, its kernels and one download instead of three round trips.
 
 A DeviceArray quacks like the float32 ndarray the reference returns: `np.asarray(x)` (or any NumPy function, arithmetic,
-indexing, attribute access) materialises it once and caches the host copy.  It is NOT an ndarray instance; code that needs
-`isinstance(x, np.ndarray)` calls `np.asarray(x)` first, or switches laziness off with `pysp_amd.set_lazy(False)`
+indexing, item assignment, in-place arithmetic, attribute access) materialises it once.  From that moment the HOST copy is the
+array: the device copy is released, so an edit through the ndarray (`a = np.asarray(x); a *= k`, `x[mask] = v`) is what every later
+call sees, exactly as with the reference's ndarray (a later GPU call uploads the host copy again).  It is NOT an ndarray instance;
+code that needs `isinstance(x, np.ndarray)` calls `np.asarray(x)` first, or switches laziness off with `pysp_amd.set_lazy(False)`
 (environment: PYSP_EAGER=1), after which every call returns plain ndarrays exactly like the reference.
+`copy.copy`, `copy.deepcopy` and `pickle` give a plain ndarray with the same values (a device pointer means nothing in a copy or
+in another process).  Buffer calls on the owning context are serialised by the context's lock, so an array may be read, or garbage
+collected, on another thread than the one that made it.
 """
 from __future__ import annotations
 
@@ -44,7 +49,8 @@ class DeviceArray:
         self._keepalive = None          # host data an enqueued upload / kernel chain still reads; dropped at the first synchronising call
         n = self.nbytes
         if dptr is None:
-            dptr = _lib.lib().pysp_dev_alloc(ctx.handle, ctypes.c_size_t(n))
+            with ctx.lock:
+                dptr = _lib.lib().pysp_dev_alloc(ctx.handle, ctypes.c_size_t(n))
             if not dptr:
                 raise MemoryError(_lib.last_error())
         self._ptr: Optional[int] = int(dptr)
@@ -54,17 +60,19 @@ class DeviceArray:
     def from_host(cls, ctx, a: np.ndarray) -> "DeviceArray":
         a = _lib.f32c(a)
         out = cls(ctx, a.shape)
-        _lib.check(_lib.lib().pysp_dev_upload(ctx.handle, out.ptr, _lib.ptr(a), ctypes.c_size_t(a.nbytes)))
+        with ctx.lock:
+            _lib.check(_lib.lib().pysp_dev_upload(ctx.handle, out.ptr, _lib.ptr(a), ctypes.c_size_t(a.nbytes)))
         out._keepalive = a          # the upload is enqueued: the source must outlive it (released at the first synchronising call)
         return out
 
     def release(self) -> None:
         if getattr(self, "_ptr", None):
+            ptr, self._ptr = self._ptr, None
             try:
-                _lib.lib().pysp_dev_free(self._ctx.handle, ctypes.c_void_p(self._ptr))
+                with self._ctx.lock:
+                    _lib.lib().pysp_dev_free(self._ctx.handle, ctypes.c_void_p(ptr))
             except Exception:
                 pass
-            self._ptr = None
 
     def __del__(self):
         self.release()
@@ -98,13 +106,26 @@ class DeviceArray:
         return self.size * 4
 
     def numpy(self) -> np.ndarray:
-        """The host copy (downloaded on first use, cached)."""
+        """The host copy: downloaded on first use, and from then on THE array -- the device copy is released, because the caller now
+        holds a writable ndarray whose edits the GPU copy would not see (the reference hands out plain ndarrays)."""
         if self._host is None:
             out = _lib.empty_f32(self.shape)
-            _lib.check(_lib.lib().pysp_dev_download(self._ctx.handle, _lib.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
+            with self._ctx.lock:
+                _lib.check(_lib.lib().pysp_dev_download(self._ctx.handle, _lib.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
             self._host = out
             self._keepalive = None
+            self.release()
         return self._host
+
+    # a copy / pickle is a plain ndarray: a device pointer must never exist twice, nor travel to another process
+    def __copy__(self):
+        return self.numpy().copy()
+
+    def __deepcopy__(self, memo):
+        return self.numpy().copy()
+
+    def __reduce__(self):
+        return (np.array, (self.numpy(),))
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()
@@ -117,6 +138,9 @@ class DeviceArray:
 
     def __getitem__(self, k):
         return self.numpy()[k]
+
+    def __setitem__(self, k, v):
+        self.numpy()[k] = v.numpy() if isinstance(v, DeviceArray) else v
 
     def __iter__(self):
         return iter(self.numpy())
@@ -142,6 +166,18 @@ for _n in ("add", "sub", "mul", "truediv", "floordiv", "pow", "mod", "matmul", "
     setattr(DeviceArray, f"__r{_n}__", _delegate(f"__r{_n}__"))
 for _n in ("neg", "pos", "abs", "lt", "le", "gt", "ge", "eq", "ne", "bool", "float", "int"):
     setattr(DeviceArray, f"__{_n}__", _delegate(f"__{_n}__"))
+
+
+def _inplace(name):
+    def op(self, other):            # x *= k acts on the host copy (the array from then on) and keeps the object
+        getattr(self.numpy(), name)(other.numpy() if isinstance(other, DeviceArray) else other)
+        return self
+    op.__name__ = name
+    return op
+
+
+for _n in ("iadd", "isub", "imul", "itruediv", "ifloordiv", "ipow", "imod", "iand", "ior", "ixor"):
+    setattr(DeviceArray, f"__{_n}__", _inplace(f"__{_n}__"))
 DeviceArray.__hash__ = None
 
 

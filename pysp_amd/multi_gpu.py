@@ -162,10 +162,11 @@ class BandPlan:
 
 
 def demosaic_warp_banded_dev(pipe, sub, plan: BandPlan, wb, M, coeffs, centre, scale: float = 1.0, group=None, exchange: str = "needed",
-                             via_host: bool = False, full=None, out=None, mark=None):
+                             via_host: bool = False, full=None, out=None, mark=None, stats=None):
     """Device-resident core of `demosaic_warp_banded`: `sub` holds mosaic rows [plan.r0, plan.r1) of the frame (the band
     plus its stencil halo) on the device.  `full` / `out` are optional reusable whole-frame (H,W,3) buffers.  `mark(i)`, if
     given, is called at the start of phase PHASES[i] and once more (i = 4) at the end (the benchmark records events there).
+    `stats`, if a dict, receives what this rank's exchange moved (rows and bytes received / sent, number of transfers).
     Everything is enqueued on torch's current stream; the only host waits are the two the algorithm itself needs (the row
     bounds come back from the device, and the all-gathered bounds are read to build the exchange plan)."""
     from . import _lib
@@ -188,9 +189,19 @@ def demosaic_warp_banded_dev(pipe, sub, plan: BandPlan, wb, M, coeffs, centre, s
             dist.all_gather(every, mine, group=group)
             needs = [(int(t[0]), int(t[1])) for t in every]
             mark(2)
-            exchange_rows(full, plan_row_exchange(plan.bands, needs), rank, group, via_host)
+            xfers = plan_row_exchange(plan.bands, needs)
+            if stats is not None:
+                rr = sum(r1 - r0 for s, d, r0, r1 in xfers if d == rank)
+                rs = sum(r1 - r0 for s, d, r0, r1 in xfers if s == rank)
+                stats.update(rows_received=rr, rows_sent=rs, bytes_received=rr * W * 12, bytes_sent=rs * W * 12,
+                             transfers=sum(1 for s, d, _, _ in xfers if rank in (s, d)), needed_rows=needs[rank])
+            exchange_rows(full, xfers, rank, group, via_host)
         elif exchange == "allgather":
             mark(2)
+            if stats is not None:
+                rr = H - (y1 - y0)
+                stats.update(rows_received=rr, rows_sent=(y1 - y0) * (world - 1), bytes_received=rr * W * 12, bytes_sent=(y1 - y0) * (world - 1) * W * 12,
+                             transfers=world - 1, needed_rows=None)
             allgather_bands(full, plan.bands, rank, group, via_host)
         else:
             raise ValueError("exchange must be 'needed' or 'allgather'")

@@ -206,3 +206,82 @@ def test_banded_demosaic_warp_world2_oracle_compute(exchange):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, 0, 48, True), (1, 48, 96, True)]
+
+
+# ---- BASELINE config 5 at its real geometry, 8 ranks: the band plan and the row-exchange plan ---------------
+def _warp_rows_needed(H, W, coeffs, centre, y0, y1, scale=1.0):
+    """Source rows [s0, s1) that output rows [y0, y1) of the per-channel WarpRectilinear read: dng_warp_rectilinear_coords.pyx:18-40 restated
+    for the rows of one band (float64; +-1 row of margin covers the float32 table's rounding), clipped like chan_distortion_corr.py:95-96,
+    Lanczos-4 support of cv2.remap (first tap row = cell - 3, eight rows)."""
+    xs = np.arange(W, dtype=np.float64)[None, :]
+    ys = np.arange(y0, y1, dtype=np.float64)[:, None]
+    cx, cy = (W - 1) * centre[0], (H - 1) * centre[1]
+    m = np.sqrt(max(abs(-cx), abs(W - 1 - cx)) ** 2 + max(abs(-cy), abs(H - 1 - cy)) ** 2)
+    dx, dy = (xs - cx) / m, (ys - cy) / m
+    r2 = dx * dx + dy * dy
+    lo, hi = H, 0
+    for kr0, kr1, kr2, kr3, kt0, kt1 in np.asarray(coeffs, np.float64).reshape(3, 6):
+        f = kr0 + kr1 * r2 + kr2 * r2 * r2 + kr3 * r2 * r2 * r2
+        dyt = 2.0 * kt1 * dx * dy + kt0 * (r2 + 2.0 * dy * dy)        # tangential part of the y coordinate (DNG 1.4 WarpRectilinear)
+        yp = cy + m * (dy * f + dyt)
+        my = np.clip(ys + (yp - ys) * scale, 0, H - 1)
+        cell = np.floor(my).astype(np.int64)
+        lo, hi = min(lo, int(cell.min()) - 3 - 1), max(hi, int(cell.max()) + 4 + 1 + 1)
+    return max(0, lo), min(H, hi)
+
+
+def _plan8_worker(rank, world, port, q):
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from pysp_amd.multi_gpu import BandPlan, plan_row_exchange
+        H, W, stages = 8736, 11648, 3                                   # BASELINE config 5 (SURVEY.md 8d)
+        coeffs = [[1.0, 0.01, 0.002, 0.0, 0.0, 0.0], [1.0, 0.0, 0.002, 0.0, 0.0, 0.0], [1.0, -0.01, 0.002, 0.0, 0.0, 0.0]]
+        plan = BandPlan(H, W, world, rank, stages)
+        s0, s1 = _warp_rows_needed(H, W, coeffs, (0.5, 0.5), plan.y0, plan.y1)
+        mine = torch.tensor([s0, s1], dtype=torch.int64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                    # what demosaic_warp_banded_dev does with the device's bounds
+        needs = [(int(t[0]), int(t[1])) for t in every]
+        xfers = plan_row_exchange(plan.bands, needs)
+        digest = int(hashlib.sha256(repr(xfers).encode()).hexdigest()[:12], 16)
+        all_d = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(all_d, torch.tensor([digest], dtype=torch.int64))
+        same_plan = len({int(d[0]) for d in all_d}) == 1
+        recv = sum(r1 - r0 for src, dst, r0, r1 in xfers if dst == rank)
+        sent = sum(r1 - r0 for src, dst, r0, r1 in xfers if src == rank)
+        q.put((rank, plan.y0, plan.y1, plan.r0, plan.r1, needs[rank], recv, sent, same_plan,
+               max((r1 - r0 for _, _, r0, r1 in xfers), default=0), max((abs(s - d) for s, d, _, _ in xfers), default=0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_band_and_exchange_plan_world8_real_geometry():
+    """8 gloo ranks, the 8736 x 11648 frame of BASELINE config 5 with its warp coefficients: bands tile the frame on even rows with the
+    AHD(3) halo of 20 rows; every rank derives the same exchange plan; rows move between neighbouring bands only, at most 60 per
+    transfer, and each rank receives a small fraction of what the all-gather would deliver."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_plan8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    H = 8736
+    assert res[0][1] == 0 and res[-1][2] == H
+    for i, (rank, y0, y1, r0, r1, need, recv, sent, same_plan, biggest, reach) in enumerate(res):
+        assert rank == i and y0 % 2 == 0 and y1 % 2 == 0 and (i == 0 or y0 == res[i - 1][2])
+        assert r0 == max(0, y0 - 20) and r1 == min(H, y1 + 20)                          # ahd_halo_rows(3) = 20
+        assert same_plan
+        assert need[0] <= y0 and need[1] >= y1 or (need[0] >= 0 and need[1] <= H)       # the band's own rows are part of what its warp reads
+        assert biggest <= 60 and reach <= 1                                             # neighbours only, <= 60 rows per transfer
+        assert recv <= 120 and recv < (H - (y1 - y0)) // 50                             # all-gather: H - band rows received per rank
+    assert sum(r[6] for r in res) == sum(r[7] for r in res) > 0

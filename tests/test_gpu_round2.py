@@ -364,6 +364,65 @@ def test_readme_recipe_stays_on_the_gpu_until_read(orc, wbobj):
         pysp_amd.set_lazy(True)
 
 
+def test_lazy_array_edits_copies_and_threads(orc, wbobj):
+    """once a host copy of a lazy array has been handed out it IS the array (an edit through it is what later calls see, as with the
+    reference's ndarray); item assignment and in-place arithmetic work; copy / deepcopy / pickle give plain ndarrays (a device pointer is never
+    duplicated); a Context cannot be copied; an array may be read and dropped on another thread."""
+    import copy
+    import pickle
+    import threading
+    from pysp_amd import DeviceArray, _lib
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    bay = rggb_frame(64, 96, 5)
+
+    def fresh():
+        return RawRggbBayerData(bay, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Fast).to_lin_srgb()
+    ref = orc.cam_to_rgb(orc.demosaic_eag(bay, wb), M, True)
+    # (1) edit through np.asarray, then a GPU call: the edit is honoured
+    lin = fresh()
+    assert isinstance(lin, DeviceArray) and lin.on_device
+    a = np.asarray(lin)
+    assert not lin.on_device                                   # the host copy is the array now
+    a *= np.float32(0.5)
+    assert np.array_equal(lin_srgb_to_srgb(lin), orc.lin_srgb_to_srgb(ref * np.float32(0.5)))
+    # (2) item assignment and in-place arithmetic on the lazy object itself
+    lin = fresh()
+    lin[ref > 0.5] = 0.25
+    lin += np.float32(0.125)
+    want = ref.copy(); want[ref > 0.5] = 0.25; want += np.float32(0.125)
+    assert isinstance(lin, DeviceArray) and np.array_equal(np.asarray(lin), want) and np.array_equal(lin_srgb_to_srgb(lin), orc.lin_srgb_to_srgb(want))
+    # (3) copies and pickles are ndarrays with the same values; the original keeps working
+    lin = fresh()
+    c1, c2, c3 = copy.copy(lin), copy.deepcopy(lin), pickle.loads(pickle.dumps(lin))
+    for c in (c1, c2, c3):
+        assert type(c) is np.ndarray and np.array_equal(c, ref)
+    c1[0, 0, 0] = 7.0
+    assert np.asarray(lin)[0, 0, 0] == ref[0, 0, 0]
+    dem = RawRggbBayerData(bay, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Fast)
+    dem2 = copy.deepcopy(dem)                                  # the container of the reference is deep-copyable: so is this one
+    assert np.array_equal(dem2.image, dem.image) and dem2.image is not dem.image
+    for f in (copy.copy, copy.deepcopy, pickle.dumps):
+        with pytest.raises(TypeError):
+            f(_lib.default_context())
+    # (4) another thread reads and drops a lazy array made here
+    lin = fresh()
+    box = {}
+
+    def reader(x):
+        box["v"] = np.asarray(x).copy()
+    t = threading.Thread(target=reader, args=(lin,)); t.start(); t.join()
+    assert np.array_equal(box["v"], ref)
+    lin = fresh()
+    t = threading.Thread(target=lambda holder: holder.clear(), args=([lin],))
+    del lin
+    t.start(); t.join()
+    assert np.array_equal(np.asarray(fresh()), ref)            # the context's buffer cache survived the foreign-thread free
+
+
 def test_host_pipeline_in_overlapped_bands_equals_whole_frame(orc, wbobj):
     """The host-buffer entry points cut frames of more than 4 MP into 256-row bands (upload / kernels / download overlap):
     same bits as the device-resident whole-frame call, for every quality, the HDR metric, stages 0..3 and uint16 input."""

@@ -10,6 +10,8 @@ out = {"_format": "per workload: kernel -> {hbm_bytes, valu_insts (wave-level VA
                   "WRITE_SIZE*1024 (FETCH_SIZE doubled per the gfx950 calibration in tools/ubench_fetch.hip / MI355X_MICROARCH.md section HBM)"}
 for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_pmc_*_summary.csv"))):
     wl = re.match(rf"{tag}_pmc_(.*)_summary.csv", os.path.basename(path)).group(1)
+    sha_path = path.replace("_summary.csv", "_lib.sha256")
+    sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None
     rows = {}
     for r in csv.DictReader(open(path)):
         k = r["kernel"].split("<")[0].split("(")[0].strip()
@@ -18,6 +20,6 @@ for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_pmc_*_summar
     for k, c in sorted(rows.items()):
         if "FETCH_SIZE" not in c or "SQ_INSTS_VALU" not in c: continue
         out[wl][k] = {"hbm_bytes": int(round(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)), "valu_insts": c["SQ_INSTS_VALU"], "px": PX[wl],
-                      "source": os.path.relpath(path, ROOT)}
+                      "source": os.path.relpath(path, ROOT), "lib_sha256": sha}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps({w: {k: (v["hbm_bytes"], round(v["valu_insts"] * 64 / v["px"], 1)) for k, v in d.items()} for w, d in out.items() if w != "_format"}, indent=1))

@@ -25,3 +25,5 @@ for g in "${groups[@]}"; do
   i=$((i+1))
 done
 python3 "$root/tools/pmc_summary.py" "$root/gpurun_out/pmc_$tag" > "$root/gpurun_out/pmc_${tag}_summary.csv"
+# which binary the counters describe: bench.py compares this with the library it loads (roofline.traffic_stale)
+sha256sum "${PYSP_HIP_LIB:-$root/pysp_amd/csrc/libpysp_hip.so}" | cut -d" " -f1 > "$root/gpurun_out/pmc_${tag}_lib.sha256"
