@@ -129,26 +129,14 @@ DEVI int dot2_i16(unsigned v, int w, int acc) {
 // v_mul_u32_u24 spelled out: the compiler turns __umul24 back into a plain multiply and then cannot prove (16 - f) | (f << 16) is a
 // 24-bit value, so it picks v_mul_lo_u32, which issues at a quarter of the rate
 DEVI unsigned mul24(unsigned a, unsigned b) { unsigned d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-DEVI unsigned shr_and(unsigned v, unsigned sh, unsigned mask) {
-    unsigned t, d;
-    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(t) : "v"(sh), "v"(v));
-    asm("v_and_b32 %0, %1, %2" : "=v"(d) : "v"(mask), "v"(t));
-    return d;
-}
 DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B, float& L, float& a, float& b) {
     // cvRound(clip(v) * 2^14) without a conversion: clip(v) * 2^14 + 1.5 * 2^23 is one exact-product FMA whose rounding IS round-half-even
     // to an integer, and the integer (<= 2^14) then sits in the low mantissa bits: cell = bits 9..14, position = bits 5..8.
     const unsigned bx = __float_as_uint(__builtin_fmaf(clip01_cv(R), 16384.0f, 12582912.0f));
     const unsigned by = __float_as_uint(__builtin_fmaf(clip01_cv(G), 16384.0f, 12582912.0f));
     const unsigned bz = __float_as_uint(__builtin_fmaf(clip01_cv(B), 16384.0f, 12582912.0f));
-#ifdef LAB_FULLRATE_FIELDS
-    // experiment: bit fields as shift + and (two full-rate instructions) instead of v_bfe_u32 (half rate)
-    const unsigned fx = shr_and(bx, 5, 15u), fy = shr_and(by, 5, 15u), fz = shr_and(bz, 5, 15u);
-    const unsigned tx = shr_and(bx, 9, 63u), ty = shr_and(by, 9, 63u), tz = shr_and(bz, 9, 63u);
-#else
     const unsigned fx = (bx >> 5) & 15u, fy = (by >> 5) & 15u, fz = (bz >> 5) & 15u;
     const unsigned tx = (bx >> 9) & 63u, ty = (by >> 9) & 63u, tz = (bz >> 9) & 63u;
-#endif
     // 24-bit multiplies throughout (v_mul_u32_u24 / v_mad_u32_u24 issue at the full rate, v_mul_lo_u32 at a quarter of it)
     const uint4* e = lut + 4u * (__umul24(__umul24(tz, CV410_DIM) + ty, CV410_DIM) + tx);
     const uint4 q0 = e[0], q1 = e[1], q2 = e[2];      // 12 dwords of one 64-byte line: (dz, dy) = (0,0), (0,1), (1,0), (1,1), each (L, a, b) as x pairs
@@ -159,17 +147,9 @@ DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B
     int aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 0))));
     int ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 0))));
     aL = (aL + (1 << 11)) >> 12; aa = (aa + (1 << 11)) >> 12; ab = (ab + (1 << 11)) >> 12;
-#ifdef LAB_FULLRATE_FIELDS
-    // (float)i for |i| < 2^22 as integer add + float subtract (both full rate) instead of v_cvt_f32_i32 (half rate)
-    const float fL = __int_as_float(aL + 0x4B400000) - 12582912.0f, fa = __int_as_float(aa + 0x4B400000) - 12582912.0f, fb = __int_as_float(ab + 0x4B400000) - 12582912.0f;
-    L = fL * (100.0f / 16384.0f);
-    a = fa * (256.0f / 16384.0f) - 128.0f;
-    b = fb * (256.0f / 16384.0f) - 128.0f;
-#else
     L = (float)aL * (100.0f / 16384.0f);
     a = (float)aa * (256.0f / 16384.0f) - 128.0f;
     b = (float)ab * (256.0f / 16384.0f) - 128.0f;
-#endif
 }
 
 // ---- sRGB transfer curves, transform.py:89-111 -------------------------------------------------

@@ -148,7 +148,7 @@ int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* 
 // pyx:18-40.  Cython lowers x**k on C floats to powf(x, k.0) (correctly rounded to float32 by glibc
 // in all but ~0.3 % of arguments) and sqrt to the double sqrt.  Here x**2 is the exact float32
 // product, x**4 / x**6 are float64 products rounded once, sqrt is the float64 sqrt.
-struct WarpGeom { float cx, cy, m; };
+struct WarpGeom { float cx, cy, m; double rm; };   // rm = 1 / m rounded to float64
 static WarpGeom warp_geom(int width, int height, float cxn, float cyn) {
     WarpGeom g;
     g.cx = (float)(width - 1) * cxn;
@@ -156,6 +156,7 @@ static WarpGeom warp_geom(int width, int height, float cxn, float cyn) {
     float mx = fmaxf(fabsf(-g.cx), fabsf((float)(width - 1) - g.cx));
     float my = fmaxf(fabsf(-g.cy), fabsf((float)(height - 1) - g.cy));
     g.m = (float)sqrt((double)(mx * mx + my * my));
+    g.rm = 1.0 / (double)g.m;
     return g;
 }
 struct WarpCoef { float kr0, kr1, kr2, kr3, kt0, kt1; };
@@ -163,7 +164,9 @@ struct WarpCoef { float kr0, kr1, kr2, kr3, kt0, kt1; };
 struct WarpRad { float dx, dy, dx2, dy2, r2, r4, r6; };
 DEVI WarpRad warp_rad(float sx, float sy, const WarpGeom& g) {
     WarpRad w;
-    w.dx = (sx - g.cx) / g.m; w.dy = (sy - g.cy) / g.m;
+    // a / m for the frame-constant m (pyx:26-27): float(double(a) * RN53(1 / m)) IS the correctly rounded float32 quotient (the argument of div_by_sat in
+    // demosaic_common.h) -- three instructions instead of the eleven of an IEEE float32 division (k_warp_remap at 100 MP: 2.10 -> 2.075 ms)
+    w.dx = (float)((double)(sx - g.cx) * g.rm); w.dy = (float)((double)(sy - g.cy) * g.rm);
     w.dx2 = w.dx * w.dx; w.dy2 = w.dy * w.dy;
     float r = sqrtf(w.dx2 + w.dy2);   // == float(sqrt(double(s))): the float64 sqrt rounded to float32 is the correctly rounded float32 sqrt
     double rd = (double)r, r2d = rd * rd;
@@ -240,13 +243,19 @@ constexpr int WRPT = WARP_RPT;               // output rows per thread
 constexpr int WBX = 64, WBY = 4 * WRPT;     // output block of one workgroup
 constexpr int WTW = 96, WTH = WBY + 16;     // largest per-channel source tile staged in LDS: 3 x 12 KB at 16 rows
 }
+// Round 3, measured and dropped (100 MP, tools/ab_bench.sh; this kernel 2.10 ms): one channel at a time with the rectangle stored twice, the second
+// copy shifted by one element, so that the eight taps of a row are four aligned ds_read_b64 whatever the first column's parity (25 KB of LDS, 76-102
+// VGPRs, up to six workgroups per CU): 2.64 ms with four rows per thread, 2.72 with three, 2.79 with two -- the extra barriers, the staging done three
+// times and the doubled LDS stores cost more than the halved read cycles save; LDS padding to three workgroups per CU changes nothing (2.10): the kernel is
+// bound by VALU issue (3 714 instructions per wave, 2 304 of them the taps' multiply, multiply, add) and LDS throughput (68 % busy), not by latency.
+// 16-byte reads of the x weights +1.4 %, staging loads without an exec-masked block each (select after an always-valid load) +2.8 %.
 // One workgroup = 64x16 output pixels (four rows per thread).  Each channel has its own smooth warp, so the 8x8 Lanczos footprints of
 // a block cover a small source rectangle per channel, bounded by the block's corner pixels (+2 cells): it is
 // staged in LDS once per channel (zero outside the image = BORDER_CONSTANT 0) and the 64 taps per pixel and
 // channel are conflict-free LDS reads.  A pixel whose footprint is not inside the staged rectangle (extreme
 // distortion) takes the same taps from global memory instead, so correctness never depends on the bound.
 __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
-    __shared__ float stab[256];
+    __shared__ __attribute__((aligned(16))) float stab[256];
     __shared__ float tile[3][WTH * WTW];
     __shared__ int corner[3][4][2];          // per channel: source cell (ix, iy) of the block's four corner pixels
     const int tid = threadIdx.x;
