@@ -76,7 +76,9 @@ int pysp_ctx_get_lab_mode(pysp_ctx *ctx);
 int pysp_lab_cv410_lut(int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
- * the context's stream; waits for completion). */
+ * the context's stream; waits for completion).  A host call on a frame of more than 4 MP runs in overlapped
+ * 256-row bands: the two timing queries then describe the LAST band only (about 1/16 of a 24 MP frame);
+ * time whole frames with the *_dev entry points. */
 int pysp_ctx_last_kernel_ms(pysp_ctx *ctx, float *ms);
 /* Event timing on the context's stream.  mode 0: no events are recorded (nothing but kernels is enqueued);
  * mode 1 (default): one event pair per entry-point call (pysp_ctx_last_kernel_ms); mode 2: in addition each

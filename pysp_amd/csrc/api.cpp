@@ -592,6 +592,13 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
         RESERVE(ctx, i == 0 ? S_IN : S_IN2, (size_t)max_rows * W * sizeof(T), d_in[i]);
         RESERVE(ctx, i == 0 ? S_OUT : S_OUT2, (size_t)max_rows * W * 12, d_out[i]);
     }
+    if (nb > 1 && quality == PYSP_QUALITY_BEST) {
+        // the median stages' scratch images for the LARGEST band, once: band 0 is shorter than the interior bands, and growing a slot
+        // (hipFree + hipMalloc, an implicit device synchronisation) between bands would stall the overlap on the first call
+        void* t;
+        if (st >= 1) RESERVE(ctx, S_TMP0, (size_t)max_rows * W * 12, t);
+        if (st >= 2) RESERVE(ctx, S_TMP1, (size_t)max_rows * W * 12, t);
+    }
     auto mosaic = [&](const T* d) { return sizeof(T) == 2 ? mosaic_u16(reinterpret_cast<const uint16_t*>(d), black, sat) : mosaic_f32(reinterpret_cast<const float*>(d)); };
     if (nb == 1) {
         TRY(h2d(ctx, d_in[0], bayer, px * sizeof(T)));
@@ -604,18 +611,18 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
     }
     // produced[b]: band b's kernels are enqueued and ev_done[b & 1] recorded; consumed: bands whose download has finished
-    std::atomic<int> produced{0}, consumed{0}, worker_rc{PYSP_OK};
+    std::atomic<int> produced{0}, consumed{0}, worker_rc{PYSP_OK}, worker_err{(int)hipSuccess};    // worker_err: the hipError_t the WORKER saw (hipGetLastError is per thread)
     std::atomic<bool> abort{false};
     const int device = ctx->device;
     std::thread worker([&] {
-        if (hipSetDevice(device) != hipSuccess) { worker_rc = PYSP_EHIP; consumed = nb; return; }
+        { hipError_t e0 = hipSetDevice(device); if (e0 != hipSuccess) { worker_err = (int)e0; worker_rc = PYSP_EHIP; consumed = nb; return; } }
         for (int b = 0; b < nb; b++) {
             while (produced.load(std::memory_order_acquire) <= b) { if (abort.load()) { consumed = nb; return; } std::this_thread::yield(); }
             const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H, r0 = y0 - halo > 0 ? y0 - halo : 0;
             hipError_t e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0);
             if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)y0 * W * 3, d_out[i] + (size_t)(y0 - r0) * W * 3, (size_t)(y1 - y0) * W * 12, hipMemcpyDeviceToHost, ctx->copy_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
-            if (e != hipSuccess) worker_rc = PYSP_EHIP;
+            if (e != hipSuccess) { worker_err = (int)e; worker_rc = PYSP_EHIP; }
             consumed.store(b + 1, std::memory_order_release);
         }
     });
@@ -635,7 +642,7 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     if (rc != PYSP_OK) abort = true;
     worker.join();
     if (rc != PYSP_OK) return rc;
-    if (worker_rc.load() != PYSP_OK) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(hipGetLastError()));
+    if (worker_rc.load() != PYSP_OK) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString((hipError_t)worker_err.load()));
     return pysp_ctx_sync(ctx);
 }
 static int run_pipeline_host(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr,

@@ -231,12 +231,11 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     // One 8-byte load per quad row; a thread's loads are all issued before its first LDS store.
     {
         constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT_A - 1) / NT_A;
-        static_assert(LAB_SLOTS % NT_A == 0, "table copy assumes whole rounds");
-        constexpr int NTAB = LAB == 0 ? LAB_SLOTS / NT_A : 0;
+        constexpr int NTAB = LAB == 0 ? (LAB_SLOTS + NT_A - 1) / NT_A : 0;
         float2 tmp[NL];
         float4 ttab[NTAB + 1];
 #pragma unroll
-        for (int k = 0; k < NTAB; k++) ttab[k] = p.labtab[tid + k * NT_A];
+        for (int k = 0; k < NTAB; k++) ttab[k] = p.labtab[min(tid + k * NT_A, LAB_SLOTS - 1)];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             int idx = tid + k * NT_A;
@@ -264,7 +263,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             }
         }
 #pragma unroll
-        for (int k = 0; k < NTAB; k++) s_labtab[tid + k * NT_A] = ttab[k];
+        for (int k = 0; k < NTAB; k++) if (tid + k * NT_A < LAB_SLOTS) s_labtab[tid + k * NT_A] = ttab[k];
     }
     __syncthreads();
 
