@@ -281,7 +281,7 @@ def test_config5_band_and_exchange_plan_world8_real_geometry():
         assert rank == i and y0 % 2 == 0 and y1 % 2 == 0 and (i == 0 or y0 == res[i - 1][2])
         assert r0 == max(0, y0 - 20) and r1 == min(H, y1 + 20)                          # ahd_halo_rows(3) = 20
         assert same_plan
-        assert need[0] <= y0 and need[1] >= y1 or (need[0] >= 0 and need[1] <= H)       # the band's own rows are part of what its warp reads
+        assert 0 <= need[0] < need[1] <= H and need[0] < y1 and need[1] > y0              # what a band's warp reads overlaps the band itself
         assert biggest <= 60 and reach <= 1                                             # neighbours only, <= 60 rows per transfer
         assert recv <= 120 and recv < (H - (y1 - y0)) // 50                             # all-gather: H - band rows received per rank
     assert sum(r[6] for r in res) == sum(r[7] for r in res) > 0

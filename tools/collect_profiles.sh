@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU-box call that produces every measurement artefact of a round (copied into profiles/ afterwards):
-#   bash tools/collect_profiles.sh r2      (through gpurun; results under gpurun_out/<tag>_final/)
+#   bash tools/collect_profiles.sh r3      (through gpurun; results under gpurun_out/<tag>_final/)
 # rocprofv3 runs the program itself (python3 bench.py ...), never a shell or env wrapper; --pmc passes are separate from the stats pass.
 set -o pipefail
-tag=${1:-r2}
+tag=${1:-r3}
 root=$(pwd)
 out=$root/gpurun_out/${tag}_final
 mkdir -p "$out"
@@ -29,10 +29,13 @@ bash "$root/tools/pmc_collect.sh" ${tag}_ahd24 > "$out/pmc_ahd24.log" 2>&1
 bash "$root/tools/pmc_collect.sh" ${tag}_eag24ccm --workload eag24ccm > "$out/pmc_eag.log" 2>&1
 bash "$root/tools/pmc_collect.sh" ${tag}_draft12 --workload draft12 > "$out/pmc_draft.log" 2>&1
 bash "$root/tools/pmc_collect.sh" ${tag}_warp100 --workload warp100 > "$out/pmc_warp.log" 2>&1
-for k in ahd24 eag24ccm draft12 warp100; do cp "$root/gpurun_out/pmc_${tag}_${k}_summary.csv" "$out/pmc_${k}_summary.csv"; done
+for k in ahd24 eag24ccm draft12 warp100; do cp "$root/gpurun_out/pmc_${tag}_${k}_summary.csv" "$out/pmc_${k}_summary.csv"; cp "$root/gpurun_out/pmc_${tag}_${k}_lib.sha256" "$out/pmc_${k}_lib.sha256"; done
 echo "pmc done"
 # 5. PCIe-inclusive timings of the drop-in API, whole configs 4 / 5 on one GPU
 python3 "$root/tools/dropin_time.py" > "$out/dropin_time.log" 2>&1
 python3 "$root/tools/config_time.py" > "$out/config_time.log" 2>&1
 python3 "$root/tests/ref_native_time.py" gpu > "$out/native_units_gpu.log" 2>&1
+# 6. the microbenchmarks behind the issue-cost model and the stream ceilings (binaries built by `make -C tools` / hipcc before the call)
+[ -x "$root/tools/ubench_valu3.bin" ] && "$root/tools/ubench_valu3.bin" > "$out/ubench_valu.log" 2>&1
+[ -x "$root/tools/ubench_stream.bin" ] && "$root/tools/ubench_stream.bin" > "$out/ubench_stream.log" 2>&1
 echo "all done"
