@@ -46,6 +46,13 @@ class RawDemosaicData:
         else:
             self._dev, self._img = None, (value.numpy() if isinstance(value, DeviceArray) else value)
 
+    def __getstate__(self):
+        """State for copy / deepcopy / pickle: the image as a host ndarray (a device buffer is never copied or sent to another process)."""
+        st = self.__dict__.copy()
+        if st.get("_dev") is not None:
+            st["_img"], st["_dev"] = st["_dev"].numpy(), None
+        return st
+
     def is_valid(self) -> bool:
         """Image, coefficients, matrix and exposure value are all present."""
         have = (self._dev is not None or self._img is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
