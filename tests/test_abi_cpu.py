@@ -289,3 +289,32 @@ def test_pinned_result_pool_bounds_and_reentrancy(monkeypatch):
     del keep; gc.collect()
     hp.trim()
     assert hp._idle == 0 and not hp._free
+
+
+def test_bench_verify_helpers_and_cpu_team_report(monkeypatch):
+    """bench.py's verify leg: ulp_compare counts differing float32 values and their largest distance in ULPs (NaN == NaN, +0 == -0, the
+    distance runs across zero); the oracle's OpenMP team size is reported with the reason for any cap."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = np.array([1.0, 2.0, np.nan, 0.0, -1.0, 1e-45, np.inf], np.float32)
+    b = a.copy()
+    assert bench.ulp_compare(np, a, b) == (0, 0)
+    b[1] = np.nextafter(np.float32(2), np.float32(3)); b[3] = -0.0; b[4] = np.nextafter(np.nextafter(np.float32(-1), np.float32(0)), np.float32(0))
+    assert bench.ulp_compare(np, a, b) == (2, 2)
+    b = a.copy(); b[5] = -1e-45                                   # smallest denormals either side of zero: two steps apart
+    assert bench.ulp_compare(np, a, b) == (1, 2)
+    b = a.copy(); b[2] = 1.0                                      # NaN against a number counts as a difference
+    assert bench.ulp_compare(np, a, b)[0] == 1
+    from oracle import oracle
+    monkeypatch.setenv("OMP_NUM_THREADS", "3")
+    assert oracle.threads() == 3 and oracle.thread_cap_reason() == "OMP_NUM_THREADS"
+    monkeypatch.delenv("OMP_NUM_THREADS")
+    monkeypatch.setattr(oracle, "_cgroup_cpu_quota", lambda: 16.0)
+    n, why = oracle._team()
+    assert n == min(16, len(os.sched_getaffinity(0))) and "cgroup CPU quota 16" in why
+    monkeypatch.setattr(oracle, "_cgroup_cpu_quota", lambda: None)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    n, why = oracle._team()
+    assert n == 16 and "256 cores visible" in why
