@@ -315,13 +315,15 @@ def main() -> None:
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0            # this rank's own K steps, before it waits for the others
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rank_ms = None
     if dist is not None:
-        # every rank's own time over the K steps (the reported time is the maximum), and for cfg5 what each rank's row exchange moved
-        mine = [elapsed / args.steps * 1e3]
+        # every rank's own time over the K steps, taken before the closing barrier (the reported time is the maximum over ranks of the
+        # barrier-to-barrier time), and for cfg5 what each rank's row exchange moved
+        mine = [own_elapsed / args.steps * 1e3]
         if args.workload == "cfg5":
             mine += [float(xstats.get("bytes_received", 0)), float(xstats.get("bytes_sent", 0)), float(xstats.get("rows_received", 0))]
         t = torch.tensor(mine, dtype=torch.float64, device=coll_dev)

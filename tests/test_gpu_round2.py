@@ -246,6 +246,12 @@ def test_bench_starts_its_own_ranks_cfg5_banded():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["bands"] == 2 and line["config"]["backend"] == "gloo"
     assert set(line["phases_ms"]) == {"demosaic", "bound_allgather", "row_exchange", "warp"} and line["phases_ms"]["demosaic"] > 0
     assert line["value"] > 0 and line["roofline"]["kernel"] in ("k_ahd_median_stage", "k_ahd_select", "k_warp_remap")
+    # round 3: every rank's own time and what its row exchange moved (a fraction of what the all-gather would deliver)
+    rk = line["ranks_ms_per_step"]
+    assert len(rk["per_rank"]) == 2 and rk["min"] <= rk["median"] <= rk["max"] and rk["max"] <= line["ms_per_step"] * 1.05
+    got, would = rk["exchange_bytes_received_per_rank"], rk["allgather_bytes_received_per_rank_would_be"]
+    assert all(0 < g < w // 20 for g, w in zip(got, would)) and sum(got) == sum(rk["exchange_bytes_sent_per_rank"])
+    assert all(r <= 120 for r in rk["exchange_rows_received_per_rank"])
 
 
 def test_bench_cfg3_batch_two_ranks_and_single():
@@ -285,6 +291,11 @@ def test_bench_default_line_contract():
     assert r["valu"] and 0 < r["valu"]["frac_of_2cycle_issue"] <= 1.0 and r["valu"]["insts_per_px"] > 100
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert c["threads_used"] == c["cores"] and c["cores_available"] >= c["cores"] and c["thread_cap"]
+    # round 3: the line verifies itself -- the GPU output of the timed whole-frame call against the oracle, bit for bit -- and says whether its PMC figures belong to this build
+    v = line["verify"]
+    assert v["frames"] >= 1 and v["max_ulp"] == 0 and v["bit_exact"] and v["bit_exact_demosaic"] and v["values_compared"] == v["frames"] * 4000 * 6000 * 3
+    assert r["traffic_stale"] in (False, True) and r["valu_insts_per_px"] == r["valu"]["insts_per_px"] and len(r["lib_sha256"]) == 64
 
 
 # ---- the sRGB curve, every float32 in [0, 1] --------------------------------------------------------
