@@ -103,6 +103,53 @@ DEVI void filt_base_br(const Win3& w, float o[4]) {  // base position BOTTOM_RIG
 }
 #undef P2
 
+// The same two filter sets on PAIRS of planes at once (experiment: a plane pair stored interleaved, e.g. { green, colour difference } of one site type,
+// loads as 8-byte LDS reads and filters as v_pk_mul / v_pk_add / v_pk_fma_f32: one half-rate instruction for two results instead of two
+// full-rate ones; each lane of a packed instruction rounds exactly like the scalar instruction).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Win3x2 { v2f v[3][3]; };
+template <int STRIDE>
+DEVI Win3x2 load_win2(const v2f* plane, int gy, int gx) {
+    Win3x2 w;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) w.v[r][c] = plane[(gy - 1 + r) * STRIDE + (gx - 1 + c)];
+    return w;
+}
+#define P2V(k, v) s = __builtin_elementwise_fma((v2f){k, k}, v, s)
+DEVI void filt_base_tl2(const Win3x2& w, v2f o[4]) {  // base position TOP_LEFT (red)
+    v2f s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.015625f, w.v[0][0]); s = s + 0.09375f * w.v[0][1]; P2V(0.015625f, w.v[0][2]);
+    s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
+    P2V(0.015625f, w.v[2][0]); s = s + 0.09375f * w.v[2][1]; P2V(0.015625f, w.v[2][2]);
+    o[0] = s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.0625f, w.v[0][1]); P2V(0.0625f, w.v[0][2]); s = s + 0.375f * w.v[1][1];
+    s = s + 0.375f * w.v[1][2]; P2V(0.0625f, w.v[2][1]); P2V(0.0625f, w.v[2][2]);
+    o[1] = s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.0625f, w.v[1][0]); s = s + 0.375f * w.v[1][1]; P2V(0.0625f, w.v[1][2]);
+    P2V(0.0625f, w.v[2][0]); s = s + 0.375f * w.v[2][1]; P2V(0.0625f, w.v[2][2]);
+    o[2] = s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.25f, w.v[1][1]); P2V(0.25f, w.v[1][2]); P2V(0.25f, w.v[2][1]); P2V(0.25f, w.v[2][2]);
+    o[3] = s;
+}
+DEVI void filt_base_br2(const Win3x2& w, v2f o[4]) {  // base position BOTTOM_RIGHT (blue)
+    v2f s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.25f, w.v[0][0]); P2V(0.25f, w.v[0][1]); P2V(0.25f, w.v[1][0]); P2V(0.25f, w.v[1][1]);
+    o[0] = s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.0625f, w.v[0][0]); s = s + 0.375f * w.v[0][1]; P2V(0.0625f, w.v[0][2]);
+    P2V(0.0625f, w.v[1][0]); s = s + 0.375f * w.v[1][1]; P2V(0.0625f, w.v[1][2]);
+    o[1] = s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.0625f, w.v[0][0]); P2V(0.0625f, w.v[0][1]); s = s + 0.375f * w.v[1][0];
+    s = s + 0.375f * w.v[1][1]; P2V(0.0625f, w.v[2][0]); P2V(0.0625f, w.v[2][1]);
+    o[2] = s;
+    s = (v2f){0.0f, 0.0f}; P2V(0.015625f, w.v[0][0]); s = s + 0.09375f * w.v[0][1]; P2V(0.015625f, w.v[0][2]);
+    s = s + 0.09375f * w.v[1][0]; s = s + 0.5625f * w.v[1][1]; s = s + 0.09375f * w.v[1][2];
+    P2V(0.015625f, w.v[2][0]); s = s + 0.09375f * w.v[2][1]; P2V(0.015625f, w.v[2][2]);
+    o[3] = s;
+}
+#undef P2V
+
 // g - GaussianBlur3(g) on the 4x4 full-resolution window around a quad (ahd.py:120-121)
 DEVI void highpass_quad(const float W[4][4], float hf[4]) {
     float rb[4][2];

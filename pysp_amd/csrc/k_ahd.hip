@@ -337,7 +337,8 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             }
             float hf[4];
             highpass_quad(Wn, hf);
-            float fg[4], fd[4], rr[4], bb[4];
+            float rr[4], bb[4];
+            float fg[4], fd[4];
             filt_base_tl(wgr, fg);
             { Win3 wd = load_win<GX>(dR, gy, gx); filt_base_tl(wd, fd); }
 #pragma unroll

@@ -6,7 +6,8 @@
 // EAG kernel: one workgroup = one 64x32 px output tile = 32x16 CFA quads, one thread per quad.
 //   P0  raw mosaic -> four de-interleaved quarter planes in LDS (halo 2 quads, symmetric border)
 //   P1  gradient-weighted green at R/B sites * wb[1], colour differences D = sub*wb - g
-//       (halo 1 quad; outside the image: REFLECT_101 of the quarter plane)
+//       (halo 1 quad; outside the image: REFLECT_101 of the quarter plane), stored as PAIRS { g, D } per site type: the 3x3 windows load as
+//       8-byte LDS reads and both photosite filter sets run as v_pk_mul / v_pk_add / v_pk_fma_f32 (round 3: -1.6 %)
 //   P2  per quad: g - GaussianBlur3(g), photosite-aware resampling of R and B, colour tail, store
 #include "demosaic_common.h"
 #include "kernels.h"
@@ -21,7 +22,6 @@ constexpr int MWX = TQX + 4, MWY = TQY + 4;   // raw planes, halo 2 quads
 constexpr int GX = TQX + 2, GY = TQY + 2;     // green / difference planes, halo 1 quad
 constexpr int NT = TQX * TQY;                 // 512
 enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
-enum { Q_GR = 0, Q_GB, Q_DR, Q_DB };
 
 // edge_assisted_gaussian.py:36-49
 DEVI float delta_mix(float top, float bottom, float left, float right) {
@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     constexpr int NPLANES = 4 * MWY * MWX + 4 * GY * GX, NSTAGE = (2 * TQY) * (2 * TQX * 3);
     __shared__ __attribute__((aligned(16))) float lds[NPLANES > NSTAGE ? NPLANES : NSTAGE];
     float (*mw)[MWY][MWX] = reinterpret_cast<float (*)[MWY][MWX]>(lds);
-    float (*gq)[GY][GX] = reinterpret_cast<float (*)[GY][GX]>(lds + 4 * MWY * MWX);
+    v2f (*gq2)[GY][GX] = reinterpret_cast<v2f (*)[GY][GX]>(lds + 4 * MWY * MWX);      // [0] = { green at R sites, R - green }, [1] = the same at B sites
+    static_assert((4 * MWY * MWX) % 2 == 0, "8-byte aligned pairs");
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
     int tbx, tby;
@@ -131,9 +132,8 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
         }
         float gr = delta_mix(mw[P_G2][a - 1][c], mw[P_G2][a][c], mw[P_G1][a][c - 1], mw[P_G1][a][c]) * p.wb[1];
         float gb = delta_mix(mw[P_G1][a][c], mw[P_G1][a + 1][c], mw[P_G2][a][c], mw[P_G2][a][c + 1]) * p.wb[1];
-        gq[Q_GR][gy][gx] = gr; gq[Q_GB][gy][gx] = gb;
-        gq[Q_DR][gy][gx] = mw[P_R][a][c] * p.wb[0] - gr;
-        gq[Q_DB][gy][gx] = mw[P_B][a][c] * p.wb[2] - gb;
+        gq2[0][gy][gx] = (v2f){gr, mw[P_R][a][c] * p.wb[0] - gr};
+        gq2[1][gy][gx] = (v2f){gb, mw[P_B][a][c] * p.wb[2] - gb};
     }
     __syncthreads();
 
@@ -148,7 +148,12 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
     const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
     const float wg = p.wb[1];
-    Win3 wgr = load_win<GX>(&gq[Q_GR][0][0], gy, gx), wgb = load_win<GX>(&gq[Q_GB][0][0], gy, gx);
+    const Win3x2 wr2 = load_win2<GX>(&gq2[0][0][0], gy, gx), wb2 = load_win2<GX>(&gq2[1][0][0], gy, gx);
+    Win3 wgr, wgb;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { wgr.v[r][c] = wr2.v[r][c].x; wgb.v[r][c] = wb2.v[r][c].x; }
     float g1_c = mw[P_G1][my][mx] * wg, g2_c = mw[P_G2][my][mx] * wg;
     float Wn[4][4] = {{wgb.v[0][0], mw[P_G2][my - 1][mx] * wg, wgb.v[0][1], mw[P_G2][my - 1][mx + 1] * wg},
                       {mw[P_G1][my][mx - 1] * wg, wgr.v[1][1], g1_c, wgr.v[1][2]},
@@ -166,16 +171,17 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
             if (at_right) Wn[k][3] = Wn[k][1];
         }
     }
-    float hf[4], fg[4], fd[4], rr[4], bb[4];
+    float hf[4], rr[4], bb[4];
     highpass_quad(Wn, hf);                                           // eag.py:156
-    filt_base_tl(wgr, fg);
-    { Win3 wd = load_win<GX>(&gq[Q_DR][0][0], gy, gx); filt_base_tl(wd, fd); }
+    {
+        v2f o2[4];
+        filt_base_tl2(wr2, o2);
 #pragma unroll
-    for (int k = 0; k < 4; k++) rr[k] = fd[k] + (fg[k] + hf[k]);     // eag.py:141,143
-    filt_base_br(wgb, fg);
-    { Win3 wd = load_win<GX>(&gq[Q_DB][0][0], gy, gx); filt_base_br(wd, fd); }
+        for (int k = 0; k < 4; k++) rr[k] = o2[k].y + (o2[k].x + hf[k]);     // eag.py:141,143
+        filt_base_br2(wb2, o2);
 #pragma unroll
-    for (int k = 0; k < 4; k++) bb[k] = fd[k] + (fg[k] + hf[k]);
+        for (int k = 0; k < 4; k++) bb[k] = o2[k].y + (o2[k].x + hf[k]);
+    }
     float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
