@@ -40,6 +40,18 @@ constexpr int NT_A = LQX * LQY;                    // 256: one thread per quad o
 
 constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // ahd.py:89-94
 
+// Diagnostic build only (-DAHD_STAMPS, tools/phase_stamps.py): wave 0..3 of every workgroup writes the shader clock (s_memtime) at the phase
+// boundaries of k_ahd_select into a device array that no kernel reads; pysp_debug_ahd_stamps copies it out.  Never part of the product build.
+#ifdef AHD_STAMPS
+constexpr int AHD_NSTAMP = 16, AHD_STAMP_WAVES = 1 << 17;
+__device__ unsigned long long g_ahd_stamps[(size_t)AHD_NSTAMP * AHD_STAMP_WAVES];
+#define AHD_STAMP(i) do { if ((threadIdx.x & 63) == 0) { \
+        const unsigned wv_ = (blockIdx.y * gridDim.x + blockIdx.x) * (NT_A / 64) + (threadIdx.x >> 6); \
+        if (wv_ < (unsigned)AHD_STAMP_WAVES) g_ahd_stamps[(size_t)wv_ * AHD_NSTAMP + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define AHD_STAMP(i) do { } while (0)
+#endif
+
 enum { P_R = 0, P_G1 = 1, P_G2 = 2, P_B = 3 };
 
 // ahd.py:32-62: second white balance, CCM without clip, (HDR: luma + x/(1+x)), Lab
@@ -219,6 +231,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
 
     const int tid = threadIdx.x;
+    AHD_STAMP(0);
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
     int tbx, tby;
     xcd_tile(tbx, tby);
@@ -265,7 +278,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 #pragma unroll
         for (int k = 0; k < NTAB; k++) if (tid + k * NT_A < LAB_SLOTS) s_labtab[tid + k * NT_A] = ttab[k];
     }
+    AHD_STAMP(1);      // P0 done (tile loaded, planes stored)
     __syncthreads();
+    AHD_STAMP(2);
 
 #define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
     // ---- P1(dir): directional green at R/B sites (ahd.py:97-102) and D = sub - g (eag.py:142) of ONE direction into gq
@@ -293,7 +308,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         }
     };
     green_planes(0);
+    AHD_STAMP(3);      // P1(H) done
     __syncthreads();
+    AHD_STAMP(4);
 
     const int lqy = tid / LQX, lqx = tid - lqy * LQX;
     const int qi = tq0y - 1 + lqy, qj = tq0x - 1 + lqx;
@@ -362,7 +379,9 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 #endif
             }
         }
+        AHD_STAMP(dir == 0 ? 5 : 9);      // P2 done
         __syncthreads();   // Lab of this direction complete; every thread is done with gq
+        AHD_STAMP(dir == 0 ? 6 : 10);
 
         // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 Lab window
         if (active) {
@@ -404,11 +423,15 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         }
         if (dir == 0) {
             green_planes(1);   // the vertical planes replace the horizontal ones while the horizontal votes read the Lab buffer
+            AHD_STAMP(7);      // P3(H) + P1(V) done
             __syncthreads();   // ... and the next P2 writes the Lab buffer only after every vote of this direction has read it
+            AHD_STAMP(8);
         }
     }
 #undef MWAT
+    AHD_STAMP(11);             // P3(V) done
     __syncthreads();
+    AHD_STAMP(12);
 
     // ---- P4: 3x3 box (cv2.blur, REFLECT_101; integer sums order like the float means), select, store
     if (inner) {
@@ -440,6 +463,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         // two rows of three 8-byte stores instead of twelve dword stores; uniform tile origin + tile-local 32-bit offset (inner: lqy, lqx >= 1)
         store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, lqy - 1, lqx - 1, px);
     }
+    AHD_STAMP(13);             // P4 done (stores issued)
 }
 
 // ================================================================================================
@@ -776,3 +800,17 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+#ifdef AHD_STAMPS
+// diagnostic build: the stamp array of the last k_ahd_select launches (AHD_NSTAMP values per wave, zero where never written)
+extern "C" int pysp_debug_ahd_stamps(unsigned long long* out, size_t n_values, int clear) {
+    const size_t total = (size_t)AHD_NSTAMP * AHD_STAMP_WAVES;
+    if (n_values > total) n_values = total;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ahd_stamps), n_values * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ahd_stamps)) != hipSuccess || hipMemset(p, 0, total * sizeof(unsigned long long)) != hipSuccess) return -3;
+    }
+    return AHD_NSTAMP;
+}
+#endif
