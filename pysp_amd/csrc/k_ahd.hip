@@ -122,8 +122,8 @@ DEVI void load_lab_rows(const float* plane, int lqy, int lqx, bool at_top, bool 
 // DIR 1: from the up/down neighbours (map_v).  The centre and the two epsilon neighbours always count:
 // x - c <= max(|c - x|, .) and the chroma distance of a neighbour is one of the two maximised squares
 // (d*d == (-d)*(-d) bit for bit), so only the other six window cells are tested.
-// (Measured and dropped: evaluating the six pixel pairs inside the quad once for both of their pixels saves 36 of
-// ~240 operations per direction but costs 12-16 VGPRs: 3-25 % slower at 165 VGPRs, +-0.5 % at 137 (SLP threshold 20).)
+// (Round 1 measured and dropped the sharing of the quad's six pixel pairs below: it cost 12-16 VGPRs in a kernel that had 137-165 of them.
+// With the vote split into two row pieces it costs none: vote_quad below.)
 // c + (lane's bit of m): the two compares of a cell leave their results in scalar register pairs, their AND is a scalar instruction, and
 // v_addc_co_u32 takes such a pair as its carry-in -- one vector instruction per cell instead of v_cndmask(0, 1) + v_add
 DEVI int add_lane_bit(int c, unsigned long long m) {
@@ -131,18 +131,34 @@ DEVI int add_lane_bit(int c, unsigned long long m) {
     asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(carry_out) : "v"(c), "s"(m));
     return d;
 }
-template <int DIR, int K0 = 0, int K1 = 4>
-DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4]) {
+// Round 3: the chroma distances BETWEEN the four pixels of the quad are computed once for both pixels of a pair: (a_q - a_p)^2 + (b_q - b_p)^2 has
+// the same bits seen from p and from q, every pixel of the quad lies in every other's 3x3 window, and of the six pairs each is needed twice (as a tested
+// cell or as an epsilon neighbour).  The pair is computed by its lower-numbered pixel and reused by the higher one (pc[]: (0,1) (2,3) (0,2) (1,3) (0,3) (1,2));
+// the four pairs that join the upper and the lower pixel row cross from the first vote piece to the second in four registers
+// (60 of the kernel's 2 240 instructions, 71 VGPRs; 0.6110 -> 0.6053 ms per step in six A/B runs each, profiles/r3_ab_select_pairshare.log).
+constexpr int quad_pair_id(int a, int b) {
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return lo == 0 ? (hi == 1 ? 0 : hi == 2 ? 2 : 4) : lo == 1 ? (hi == 3 ? 3 : 5) : 1;
+}
+template <int DIR, int K0, int K1>
+DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4], float pc[6]) {
 #pragma unroll
     for (int k = K0; k < K1; k++) {
         const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
         const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
-        float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
-        float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
-        float da1 = ra - wa[n1y][n1x], db1 = rb - wq[n1y][n1x], da2 = ra - wa[n2y][n2x], db2 = rb - wq[n2y][n2x];
-        float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
-        // Cython's max(a, b) = (b > a) ? b : a.  Here every operand is finite and non-negative (this form only runs where Lab is finite:
-        // the HDR metric, whose L may not be, takes the literal form below), so one raw v_max_f32 returns the same bits as compare + select.
+        const float rl = wl[cy][cx], ra = wa[cy][cx], rb = wq[cy][cx];
+        // chroma distance to window position (y, x): from the pair table when that position is another pixel of the quad
+        auto dist = [&](const int y, const int x) -> float {
+            const bool quad = y >= 1 && y <= 2 && x >= 1 && x <= 2;
+            const int q = quad ? (y - 1) * 2 + (x - 1) : -1;
+            if (quad && q < k) return pc[quad_pair_id(k, q)];
+            const float da = wa[y][x] - ra, db = wq[y][x] - rb;
+            const float d = da * da + db * db;
+            if (quad) pc[quad_pair_id(k, q)] = d;
+            return d;
+        };
+        const float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
+        const float c1 = dist(n1y, n1x), c2 = dist(n2y, n2x);
         float el, ec;
         asm("v_max_f32 %0, %1, %2" : "=v"(el) : "v"(e1), "v"(e2));
         asm("v_max_f32 %0, %1, %2" : "=v"(ec) : "v"(c1), "v"(c2));
@@ -153,8 +169,7 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
             for (int wx = 0; wx < 3; wx++) {
                 const int y = dy + wy, x = dx + wx;
                 if ((y == cy && x == cx) || (y == n1y && x == n1x) || (y == n2y && x == n2x)) continue;
-                float da = wa[y][x] - ra, db = wq[y][x] - rb;
-                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(wl[y][x] - rl <= el) & __builtin_amdgcn_ballot_w64(da * da + db * db <= ec));
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(wl[y][x] - rl <= el) & __builtin_amdgcn_ballot_w64(dist(y, x) <= ec));
             }
         cnt[k] = c;
     }
@@ -395,19 +410,20 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             // HDR metric: L = luma (ahd.py:55,59) may be NaN or +-Inf, and then the comparisons the fast form takes for granted
             // are false; the literal nine-cell form is used throughout
             if (HDR) { if (dir == 0) vote_quad_literal<0>(wl, wa, wq, cnt); else vote_quad_literal<1>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0>(wl, wa, wq, cnt); else vote_quad<1>(wl, wa, wq, cnt); }
+            else { float pcw[6]; if (dir == 0) vote_quad<0, 0, 4>(wl, wa, wq, cnt, pcw); else vote_quad<1, 0, 4>(wl, wa, wq, cnt, pcw); }
 #else
             load_lab_rows<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_rows<0, 3>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_rows<0, 3>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+            float pc[6];               // chroma distances of the quad's six pixel pairs (vote_quad)
             if (HDR) { if (dir == 0) vote_quad_literal<0, 0, 2>(wl, wa, wq, cnt); else vote_quad_literal<1, 0, 2>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt); else vote_quad<1, 0, 2>(wl, wa, wq, cnt); }
+            else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 2>(wl, wa, wq, cnt, pc); }
             __builtin_amdgcn_sched_barrier(0);
             load_lab_rows<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_rows<3, 4>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_rows<3, 4>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
             if (HDR) { if (dir == 0) vote_quad_literal<0, 2, 4>(wl, wa, wq, cnt); else vote_quad_literal<1, 2, 4>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt); else vote_quad<1, 2, 4>(wl, wa, wq, cnt); }
+            else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc); }
 #endif
             if (dir == 0) {
                 hvotes = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
