@@ -141,11 +141,7 @@ constexpr int quad_pair_id(int a, int b) {
     return lo == 0 ? (hi == 1 ? 0 : hi == 2 ? 2 : 4) : lo == 1 ? (hi == 3 ? 3 : 5) : 1;
 }
 template <int DIR, int K0, int K1>
-DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4], float pc[6]
-#ifdef AHD_SHARE_DL
-                    , float pl[6]
-#endif
-                    ) {
+DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4], float pc[6]) {
 #pragma unroll
     for (int k = K0; k < K1; k++) {
         const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
@@ -161,21 +157,10 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
             if (quad) pc[quad_pair_id(k, q)] = d;
             return d;
         };
-#ifdef AHD_SHARE_DL
-        // L(y, x) - L(centre): the exact negation of what the pair's lower-numbered pixel computed (a source modifier, no instruction)
-        auto ldiff = [&](const int y, const int x) -> float {
-            const bool quad = y >= 1 && y <= 2 && x >= 1 && x <= 2;
-            const int q = quad ? (y - 1) * 2 + (x - 1) : -1;
-            if (quad && q < k) return -pl[quad_pair_id(k, q)];
-            const float d = wl[y][x] - rl;
-            if (quad) pl[quad_pair_id(k, q)] = d;
-            return d;
-        };
-        const float e1 = fabsf(ldiff(n1y, n1x)), e2 = fabsf(ldiff(n2y, n2x));
-#else
+        // (sharing L(q) - L(p) between the two pixels of a pair the same way -- the negation is a source modifier -- saves another 14 instructions and measures
+        // within noise: 0.6149 vs 0.6135 ms per step, six runs each; not kept)
         auto ldiff = [&](const int y, const int x) -> float { return wl[y][x] - rl; };
         const float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
-#endif
         const float c1 = dist(n1y, n1x), c2 = dist(n2y, n2x);
         float el, ec;
         asm("v_max_f32 %0, %1, %2" : "=v"(el) : "v"(e1), "v"(e2));
@@ -422,12 +407,6 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             float wl[4][4], wa[4][4], wq[4][4];
             int cnt[4];
             float pc[6];               // chroma distances of the quad's six pixel pairs (vote_quad)
-#ifdef AHD_SHARE_DL
-            float pl[6];
-#define AHD_PL , pl
-#else
-#define AHD_PL
-#endif
 #ifdef AHD_VOTE_WHOLE_WINDOW
             load_lab_win(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
@@ -435,19 +414,19 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             // HDR metric: L = luma (ahd.py:55,59) may be NaN or +-Inf, and then the comparisons the fast form takes for granted
             // are false; the literal nine-cell form is used throughout
             if (HDR) { if (dir == 0) vote_quad_literal<0>(wl, wa, wq, cnt); else vote_quad_literal<1>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 0, 4>(wl, wa, wq, cnt, pc AHD_PL); else vote_quad<1, 0, 4>(wl, wa, wq, cnt, pc AHD_PL); }
+            else { if (dir == 0) vote_quad<0, 0, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 4>(wl, wa, wq, cnt, pc); }
 #else
             load_lab_rows<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_rows<0, 3>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_rows<0, 3>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
             if (HDR) { if (dir == 0) vote_quad_literal<0, 0, 2>(wl, wa, wq, cnt); else vote_quad_literal<1, 0, 2>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt, pc AHD_PL); else vote_quad<1, 0, 2>(wl, wa, wq, cnt, pc AHD_PL); }
+            else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 2>(wl, wa, wq, cnt, pc); }
             __builtin_amdgcn_sched_barrier(0);
             load_lab_rows<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
             load_lab_rows<3, 4>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
             load_lab_rows<3, 4>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
             if (HDR) { if (dir == 0) vote_quad_literal<0, 2, 4>(wl, wa, wq, cnt); else vote_quad_literal<1, 2, 4>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc AHD_PL); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc AHD_PL); }
+            else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc); }
 #endif
             if (dir == 0) {
                 hvotes = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
