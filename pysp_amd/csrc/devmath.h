@@ -141,12 +141,15 @@ DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B
     const uint4* e = lut + 4u * (__umul24(__umul24(tz, CV410_DIM) + ty, CV410_DIM) + tx);
     const uint4 q0 = e[0], q1 = e[1], q2 = e[2];      // 12 dwords of one 64-byte line: (dz, dy) = (0,0), (0,1), (1,0), (1,1), each (L, a, b) as x pairs
     const unsigned wx = (16u - fx) | (fx << 16);                             // both x weights in one register; times <= 256 stays inside each half
-    const int w00 = (int)mul24(wx, mul24(16u - fy, 16u - fz)), w10 = (int)mul24(wx, mul24(fy, 16u - fz));   // (dy, dz)
-    const int w01 = (int)mul24(wx, mul24(16u - fy, fz)), w11 = (int)mul24(wx, mul24(fy, fz));
-    int aL = dot2_i16(q2.y, w11, dot2_i16(q1.z, w01, dot2_i16(q0.w, w10, dot2_i16(q0.x, w00, 0))));
-    int aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 0))));
-    int ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 0))));
-    aL = (aL + (1 << 11)) >> 12; aa = (aa + (1 << 11)) >> 12; ab = (ab + (1 << 11)) >> 12;
+    // six products instead of eight: the x pair times the two z factors first (<= 256 per half), then times the two y factors (<= 4096 per half)
+    const unsigned wxz0 = mul24(wx, 16u - fz), wxz1 = mul24(wx, fz);
+    const int w00 = (int)mul24(wxz0, 16u - fy), w10 = (int)mul24(wxz0, fy);   // (dy, dz)
+    const int w01 = (int)mul24(wxz1, 16u - fy), w11 = (int)mul24(wxz1, fy);
+    // CV_DESCALE's rounding constant 2^11 is the accumulators' start value (integer sums: any order, same bits)
+    int aL = dot2_i16(q2.y, w11, dot2_i16(q1.z, w01, dot2_i16(q0.w, w10, dot2_i16(q0.x, w00, 1 << 11))));
+    int aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 1 << 11))));
+    int ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 1 << 11))));
+    aL >>= 12; aa >>= 12; ab >>= 12;
     L = (float)aL * (100.0f / 16384.0f);
     a = (float)aa * (256.0f / 16384.0f) - 128.0f;
     b = (float)ab * (256.0f / 16384.0f) - 128.0f;
