@@ -131,6 +131,9 @@ DEVI int add_lane_bit(int c, unsigned long long m) {
     asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(d), "=s"(carry_out) : "v"(c), "s"(m));
     return d;
 }
+// (Round 3, measured and dropped: counting the six cell masks of a pixel on the scalar unit -- two full adders and a half adder on the 64-bit masks, 17 scalar
+// instructions, then three v_addc instead of six to turn the bit-sliced count into a per-lane number: 24 fewer vector instructions per thread, 136 more scalar
+// ones, 0.5992 -> 0.6011 ms per step in six runs each: the scalar instructions are not free.)
 // Round 3: the chroma distances BETWEEN the four pixels of the quad are computed once for both pixels of a pair: (a_q - a_p)^2 + (b_q - b_p)^2 has
 // the same bits seen from p and from q, every pixel of the quad lies in every other's 3x3 window, and of the six pairs each is needed twice (as a tested
 // cell or as an epsilon neighbour).  The pair is computed by its lower-numbered pixel and reused by the higher one (pc[]: (0,1) (2,3) (0,2) (1,3) (0,3) (1,2));
