@@ -351,8 +351,12 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
                 float wxr[8];
 #pragma unroll
                 for (int t = 0; t < 8; t++) wxr[t] = wx[t];
-#ifndef WARP_UNROLL_ROWS
-#pragma unroll 1   // one row per trip: the eight taps are immediate offsets from one row base (unrolled, each tap gets its own address add)
+                // eight rows unrolled (round 3: 2.070 -> 2.026 ms at 100 MP against one row per trip; a software-pipelined rolled form that requests row r + 1
+                // before accumulating row r: 2.32 ms -- profiles/r3_ab_warp_taploop.log)
+#ifdef WARP_ROLLED_ROWS
+#pragma unroll 1
+#else
+#pragma unroll
 #endif
                 for (int r = 0; r < 8; r++, trow += WTW) {
                     const float wyr = wy[r];
