@@ -347,7 +347,12 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
             float sum = 0.0f;
             const int lx = ix - tx0[c], ly = iy - ty0[c];
             if (lx >= 0 && ly >= 0 && lx + 8 <= tw[c] && ly + 8 <= th[c]) {
+#ifndef WARP_ROLLED_ROWS
+                typedef const __attribute__((address_space(3))) float* TileRow;         // an LDS pointer by type: it stays one through the asm below (a generic pointer would turn the reads into flat loads)
+                TileRow trow = (TileRow)&tile[c][ly * WTW + lx];
+#else
                 const float* trow = &tile[c][ly * WTW + lx];
+#endif
                 float wxr[8];
 #pragma unroll
                 for (int t = 0; t < 8; t++) wxr[t] = wx[t];
@@ -358,12 +363,20 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
 #else
 #pragma unroll
 #endif
-                for (int r = 0; r < 8; r++, trow += WTW) {
+                for (int r = 0; r < 8; r++) {
+#ifndef WARP_ROLLED_ROWS
+                    // a fresh base register every three rows (3 x 384 bytes is what the 8-bit dword offsets of ds_read2_b32 reach): the asm hides the sum from the
+                    // compiler, which otherwise gives every pair of taps its own v_add_u32 (576 address adds per thread, a ninth of the kernel's instructions)
+                    if (r % 3 == 0) { if (r) trow += 3 * WTW; asm("" : "+v"(trow)); }
+                    TileRow row = trow + (r % 3) * WTW;
+#else
+                    const float* row = trow + r * WTW;
+#endif
                     const float wyr = wy[r];
                     float acc = 0.0f;
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
-                        float v = trow[t] * (wyr * wxr[t]);
+                        float v = row[t] * (wyr * wxr[t]);
                         acc = t == 0 ? v : acc + v;
                     }
                     sum = sum + acc;
