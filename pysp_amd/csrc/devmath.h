@@ -172,14 +172,25 @@ DEVI float srgb_pow_5_12(float x) {   // x in [0.003, 1]
     float l2 = __builtin_amdgcn_logf(x);
     float z0 = __builtin_amdgcn_exp2f(-0.5833333f * l2);
     double xd = (double)x, zd = (double)z0;
-    double w = xd * (zd * zd), w2 = w * w, w6 = (w2 * w2) * w2;   // x^7 z^12 = (x z^2)^6 x
+#ifndef SRGB_ROUND2_CHAIN
+    // y0 = x z0 (exact: two float32 factors) serves twice, as the value to correct and on the way to x z0^2 (round 3: 14 instead of 15 float64-class
+    // instructions per value, -3 % on EAG + sRGB)
+    double y0 = xd * zd, w = y0 * zd, w2 = w * w, w6 = (w2 * w2) * w2;   // x^7 z^12 = (x z^2)^6 x
+    double r = __builtin_fma(w6, xd, -1.0);
+    double c = r * __builtin_fma(r, 13.0 / 288.0, -1.0 / 12.0);
+    double y = __builtin_fma(y0, c, y0);
+#else
+    double w = xd * (zd * zd), w2 = w * w, w6 = (w2 * w2) * w2;
     double r = __builtin_fma(w6, xd, -1.0);
     double c = r * __builtin_fma(r, 13.0 / 288.0, -1.0 / 12.0);
     double z = __builtin_fma(zd, c, zd);
     double y = xd * z;
+#endif
     // (0.41666666f - 5/12) * ln 2 = -9.934107462565104e-09 * 0.6931471805599453
     // (the factor as a float32 product, converted once, instead of a conversion and a float64 multiply: its rounding error, 2^-24 of a term below 6e-8,
-    // stays inside the budget -- the exhaustive sweep still finds 0 differences on all 1,065,357,312 inputs, round 3)
+    // stays inside the budget -- the exhaustive sweep still finds 0 differences on all 1,065,357,312 inputs, round 3.  Folding this term into c,
+    // y0 (1 + c + e), saves two more instructions and drops the cross term c e < 1e-14: 2 of the 1,065,357,312 inputs then round the other way -- not taken;
+    // without the quadratic term of c as well: 31 inputs)
     y = __builtin_fma(y, (double)(l2 * -6.885798579082628e-09f), y);
     return (float)y;
 }
