@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity run (bit-exact): python tests/fuzz_parity.py [seconds] [seed]
 Test infrastructure (it calls the CPU oracle); a 10-second slice of it runs inside the GPU suite (test_gpu_parity.py::test_fuzz_slice).
 Random even frame sizes, value distributions (uniform, heavy-tailed, saturated, zeros, negatives, tiny), qualities, HDR flag,
-post-process stage counts, colour tails, uint16 input, CA removal, raw fusion.  Stops at the first mismatch with a reproducer line."""
+post-process stage counts, colour tails, uint16 input, CA removal, raw fusion, WarpRectilinear (fused kernel vs its own tables through the oracle remap).  Stops at the first mismatch with a reproducer line."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -55,7 +55,7 @@ while time.time() < t_end:
         bay = sprinkle(rng, bay)
     wb = (1.0 / rng.uniform(0.3, 1.0, 3)).astype(np.float32)
     M = M0 * rng.uniform(0.8, 1.2, (3, 3)) if rng.random() < 0.5 else M0
-    case = int(rng.integers(0, 6))
+    case = int(rng.integers(0, 7))
     d = torch.from_numpy(bay).cuda()
     if case == 0:      # AHD with stages / hdr
         stages, hdr = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
@@ -95,6 +95,25 @@ while time.time() < t_end:
         got = d
         ref = orc.remove_ca(bay, f[0], f[1], float(wb[0]), f[2], f[3], float(wb[2]))
         tag = "ca"
+    elif case == 6:    # WarpRectilinear: the fused kernel against its own tables through the oracle's remap (bit-exact), random coefficients
+        if nonfinite:
+            n += 1; continue
+        import struct
+        from pysp_amd.dng_warp_corr import apply_opcode_3_warp
+        from pysp_amd.dng_warp_corr.dng_warp_rectilinear_coords import compute_remapping_table
+        img = rng.random((H, W, 3), dtype=np.float32)
+        mag = 10.0 ** rng.uniform(-4, -0.3)
+        cf = np.array([[1.0 + rng.normal(0, mag), rng.normal(0, mag), rng.normal(0, mag / 3), rng.normal(0, mag / 10), rng.normal(0, mag / 10), rng.normal(0, mag / 10)] for _ in range(3)])
+        cx, cy = float(rng.uniform(0.2, 0.8)), float(rng.uniform(0.2, 0.8))
+        payload = struct.pack(">I", 3) + b"".join(struct.pack(">6d", *c) for c in cf) + struct.pack(">2d", cx, cy)
+        g = img.copy()
+        apply_opcode_3_warp(g, struct.pack(">I", 1) + struct.pack(">IIII", 1, 1, 0, len(payload)) + payload)
+        ref = np.empty_like(img)
+        for c in range(3):
+            t = compute_remapping_table(*cf[c], W, H, cx, cy, 1.0)
+            ref[..., c] = orc.remap_lanczos4(np.ascontiguousarray(img[..., c]), np.clip(t[..., 0], 0, W - 1), np.clip(t[..., 1], 0, H - 1))
+        got = torch.from_numpy(g)
+        tag = "warp"
     else:              # raw HDR fusion
         K = int(rng.integers(2, 6))
         frames = [np.clip(frame(rng, H, W), 0, 1) for _ in range(K)]

@@ -665,6 +665,29 @@ def test_warp_with_prior_and_generic_remap(orc):
     assert np.array_equal(out, orc.remap_lanczos4(src, mx, my))          # explicit maps: bit-exact
 
 
+def test_warp_fused_kernel_equals_its_tables_through_the_oracle_remap(orc):
+    """apply_opcode_3_warp evaluates the WarpRectilinear polynomial inside the remap kernel (k_warp_remap: per-channel LDS rectangle, 64 taps from
+    LDS, or from global memory when the footprint leaves the rectangle).  Claim: bit-identical to the materialised form of
+    chan_distortion_corr.py:86-97 -- the table of compute_remapping_table (G7: <= 2 ULP from the reference's), np.clip, cv2.remap LANCZOS4 as the
+    oracle restates it -- for mild and extreme coefficients, sizes on both sides of the 64x16 block."""
+    import struct
+    from pysp_amd.dng_warp_corr import apply_opcode_3_warp
+    from pysp_amd.dng_warp_corr.dng_warp_rectilinear_coords import compute_remapping_table
+    for seed, (H, W), mag in ((0, (8, 9), 1e-3), (1, (61, 200), 3e-2), (2, (233, 130), 2e-1), (3, (16, 64), 1e-4), (4, (301, 402), 8e-3), (5, (97, 515), 0.6)):
+        rng = np.random.default_rng(900 + seed)
+        img = rng.random((H, W, 3), dtype=np.float32)
+        coeffs = np.array([[1.0 + rng.normal(0, mag), rng.normal(0, mag), rng.normal(0, mag / 3), rng.normal(0, mag / 10), rng.normal(0, mag / 10), rng.normal(0, mag / 10)]
+                           for _ in range(3)])
+        cx, cy = float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.3, 0.7))
+        payload = struct.pack(">I", 3) + b"".join(struct.pack(">6d", *c) for c in coeffs) + struct.pack(">2d", cx, cy)
+        got = img.copy()
+        apply_opcode_3_warp(got, struct.pack(">I", 1) + struct.pack(">IIII", 1, 1, 0, len(payload)) + payload)
+        for c in range(3):
+            t = compute_remapping_table(*coeffs[c], W, H, cx, cy, 1.0)
+            ref = orc.remap_lanczos4(np.ascontiguousarray(img[..., c]), np.clip(t[..., 0], 0, W - 1), np.clip(t[..., 1], 0, H - 1))
+            assert np.array_equal(got[..., c], ref), (seed, c)
+
+
 def test_wb_undo_apply_and_clean_xyz(orc, wbobj):
     """image_base.py:45-60 and transform.py:55-74 against the NumPy expressions they stand for."""
     from pysp_amd.base_types.image_base import RawDemosaicData
