@@ -27,6 +27,20 @@ DEVI void xcd_tile(int& bx, int& by) {
 #endif
 }
 
+// The same, with the XCD's share walked in vertical strips of SW tiles: a kernel whose tiles overlap their upper / lower neighbours by many rows (the
+// Lanczos warp: 11 of 27 source rows) finds those rows in its L2 only if the neighbour ran a moment ago -- a full tile row of a 100 MP frame is as large
+// as the L2 itself.  Within a strip tiles run row-major, strips left to right; the last strip takes whatever width is left.
+template <int SW>
+DEVI void xcd_tile_strips(int& bx, int& by) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy, lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned xcd = lin & 7u, q = n >> 3, r = n & 7u;
+    const unsigned t = xcd * q + (xcd < r ? xcd : r) + (lin >> 3);
+    const unsigned per = SW * gy, s = t / per, t2 = t - s * per, x0 = s * SW;
+    const unsigned w = gx - x0 < (unsigned)SW ? gx - x0 : (unsigned)SW;
+    const unsigned y = t2 / w;
+    by = (int)y; bx = (int)(x0 + (t2 - y * w));
+}
+
 // ---- border index rules: cv2 BORDER_REFLECT / REFLECT_101 / REPLICATE ----------
 DEVI int b_sym(int p, int n) {
     if (n == 1) return 0;

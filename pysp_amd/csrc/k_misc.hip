@@ -239,6 +239,9 @@ namespace {
 #ifndef WARP_RPT
 #define WARP_RPT 4                           // measured at 100 MP: 2 rows 2.28 ms, 3: 2.24, 4: 2.13, 5: 2.22, 6: 2.18, 8: 2.77
 #endif
+#ifndef WARP_STRIP
+#define WARP_STRIP 16
+#endif
 constexpr int WRPT = WARP_RPT;               // output rows per thread
 constexpr int WBX = 64, WBY = 4 * WRPT;     // output block of one workgroup
 constexpr int WTW = 96, WTH = WBY + 16;     // largest per-channel source tile staged in LDS: 3 x 12 KB at 16 rows
@@ -261,7 +264,14 @@ __global__ void __launch_bounds__(256) k_warp_remap(RemapParams p) {
     const int tid = threadIdx.x;
     stab[tid] = p.tab[tid];
     int tbx, tby;
+    // vertical strips of 16 blocks (round 3): a block shares 11 of its 27 source rows with the block below, and a full block row of a 100 MP frame (3.8 MB)
+    // does not survive in the 4 MB L2 until that block runs.  FETCH_SIZE 3.34 -> 1.32 GB per launch (2.7x -> 1.08x the 1.22 GB read once), L2 hit rate
+    // 45 % -> 70 %; 1.94 -> 1.92 ms: the kernel is not bound by memory (profiles/r3_ab_warp_strips.log, strips of 4 / 8 / 16 blocks; 0 = row-major)
+#if WARP_STRIP > 0
+    xcd_tile_strips<WARP_STRIP>(tbx, tby);
+#else
     xcd_tile(tbx, tby);
+#endif
     const int by0 = p.row0 + tby * WBY;
     const int x = tbx * WBX + (tid & 63), y0 = by0 + (tid >> 6) * WRPT;
     const float xmax = (float)(p.W - 1), ymax = (float)(p.H - 1);
