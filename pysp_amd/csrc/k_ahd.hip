@@ -33,7 +33,12 @@ constexpr int GX = TQX + 4, GY = TQY + 4;         // green / difference planes, 
 constexpr int LQX = TQX + 2, LQY = TQY + 2;       // Lab region in quads (halo 1 quad = 2 px)
 constexpr int LPS = 2 * LQX + 2, LPR = 2 * LQY + 2;  // Lab plane stride / rows: region + 1 px guard ring (34 x 34)
 constexpr int MPS = 2 * TQX + 4, MPR = 2 * TQY + 2;  // packed vote map (halo 1 px), stride 32 (8-byte aligned rows)
-constexpr int NT_A = LQX * LQY;                    // 256: one thread per quad of the halo-1 region
+#ifndef AHD_QPT
+#define AHD_QPT 1                                 // quads of the halo-1 region per thread (2: the thread's second quad lies LQY / 2 quad rows below the first)
+#endif
+constexpr int QPT = AHD_QPT;
+static_assert((LQX * LQY) % QPT == 0 && LQY % QPT == 0, "the region splits into QPT row blocks");
+constexpr int NT_A = LQX * LQY / QPT;              // 256: one thread per quad (QPT = 1) of the halo-1 region
 #ifndef AHD_MIN_WAVES
 #define AHD_MIN_WAVES 1                           // the allocator reaches 92 VGPRs unforced; forcing a bound on earlier versions only spilled
 #endif
@@ -333,70 +338,105 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     __syncthreads();
     AHD_STAMP(4);
 
-    const int lqy = tid / LQX, lqx = tid - lqy * LQX;
-    const int qi = tq0y - 1 + lqy, qj = tq0x - 1 + lqx;
-    const bool active = qi >= 0 && qi < h && qj >= 0 && qj < w;
-    const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
-    const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
-    // vote-map cell of this quad's top-left pixel (map origin = tile origin - 1 px)
-    const int vmy = 2 * lqy - 1, vmx = 2 * lqx - 1;
-    const bool inner = active && lqy >= 1 && lqy <= TQY && lqx >= 1 && lqx <= TQX;
+    // per quad of this thread: position in the region, image-edge flags, LDS coordinates
+    struct Quad { int lqy, lqx, gy, gx, my, mx, vmy, vmx; bool active, at_top, at_bot, at_left, at_right, inner; };
+    auto quad = [&](const int q) {
+        Quad c;
+        const int idx = tid + q * NT_A;
+        c.lqy = idx / LQX; c.lqx = idx - c.lqy * LQX;
+        const int qi = tq0y - 1 + c.lqy, qj = tq0x - 1 + c.lqx;
+        c.active = qi >= 0 && qi < h && qj >= 0 && qj < w;
+        c.at_top = qi == 0; c.at_bot = qi == h - 1; c.at_left = qj == 0; c.at_right = qj == w - 1;
+        c.gy = c.lqy + 1; c.gx = c.lqx + 1; c.my = c.lqy + 2; c.mx = c.lqx + 2;
+        c.vmy = 2 * c.lqy - 1; c.vmx = 2 * c.lqx - 1;      // vote-map cell of the quad's top-left pixel (map origin = tile origin - 1 px)
+        c.inner = c.active && c.lqy >= 1 && c.lqy <= TQY && c.lqx >= 1 && c.lqx <= TQX;
+        return c;
+    };
 
-    float rgbh[4][3], rgbv[4][3];   // both candidates stay in registers until the selection
-    unsigned hvotes = 0;            // the four horizontal counts of the quad (4 bits each) until the vertical ones exist
+    Quad qc[QPT];
+#pragma unroll
+    for (int q = 0; q < QPT; q++) qc[q] = quad(q);
+
+    float rgbh[QPT][4][3], rgbv[QPT][4][3];   // both candidates stay in registers until the selection
+    unsigned hvotes[QPT];                     // the four horizontal counts of a quad (4 bits each) until the vertical ones exist
+#pragma unroll
+    for (int q = 0; q < QPT; q++) hvotes[q] = 0;
 
     // fully unrolled: plane offsets and the vote's direction become constants
 #pragma unroll
     for (int dir = 0; dir < 2; dir++) {
         // ---- P2: high-pass of green, photosite-aware resampling of R and B, second white balance + CCM + Lab -> LDS
-        if (active) {
-            float (&rgbc)[4][3] = dir == 0 ? rgbh : rgbv;
+        float rr[QPT][4], gg[QPT][4], bb[QPT][4];
+        auto candidate = [&](const int q) {
+            const Quad& c = qc[q];
+            const int gy = c.gy, gx = c.gx, my = c.my, mx = c.mx;
             const float* gR = gq, *gB = gq + GY * GX, *dR = gq + 2 * GY * GX, *dB = gq + 3 * GY * GX;
             Win3 wgr = load_win<GX>(gR, gy, gx), wgb = load_win<GX>(gB, gy, gx);
             // the quad's own two green samples are the same in both candidates: the vertical pass takes them from the horizontal candidate's registers
-            const float g1_c = dir == 0 ? MWAT(P_G1, my, mx) : rgbh[1][1], g2_c = dir == 0 ? MWAT(P_G2, my, mx) : rgbh[2][1];
+            const float g1_c = dir == 0 ? MWAT(P_G1, my, mx) : rgbh[q][1][1], g2_c = dir == 0 ? MWAT(P_G2, my, mx) : rgbh[q][2][1];
             // full-resolution green, rows 2qi-1..2qi+2, cols 2qj-1..2qj+2
             float Wn[4][4] = {{wgb.v[0][0], MWAT(P_G2, my - 1, mx), wgb.v[0][1], MWAT(P_G2, my - 1, mx + 1)},
                               {MWAT(P_G1, my, mx - 1), wgr.v[1][1], g1_c, wgr.v[1][2]},
                               {wgb.v[1][0], g2_c, wgb.v[1][1], MWAT(P_G2, my, mx + 1)},
                               {MWAT(P_G1, my + 1, mx - 1), wgr.v[2][1], MWAT(P_G1, my + 1, mx), wgr.v[2][2]}};
             // GaussianBlur border = REFLECT_101 at full resolution: row -1 -> row 1, row H -> row H-2
-            if (at_top | at_bot | at_left | at_right) {
+            if (c.at_top | c.at_bot | c.at_left | c.at_right) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (at_top) Wn[0][k] = Wn[2][k];
-                    if (at_bot) Wn[3][k] = Wn[1][k];
+                    if (c.at_top) Wn[0][k] = Wn[2][k];
+                    if (c.at_bot) Wn[3][k] = Wn[1][k];
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (at_left) Wn[k][0] = Wn[k][2];
-                    if (at_right) Wn[k][3] = Wn[k][1];
+                    if (c.at_left) Wn[k][0] = Wn[k][2];
+                    if (c.at_right) Wn[k][3] = Wn[k][1];
                 }
             }
             float hf[4];
             highpass_quad(Wn, hf);
-            float rr[4], bb[4];
             float fg[4], fd[4];
             filt_base_tl(wgr, fg);
             { Win3 wd = load_win<GX>(dR, gy, gx); filt_base_tl(wd, fd); }
 #pragma unroll
-            for (int k = 0; k < 4; k++) rr[k] = fd[k] + (fg[k] + hf[k]);      // eag.py:141,143
+            for (int k = 0; k < 4; k++) rr[q][k] = fd[k] + (fg[k] + hf[k]);      // eag.py:141,143
             filt_base_br(wgb, fg);
             { Win3 wd = load_win<GX>(dB, gy, gx); filt_base_br(wd, fd); }
 #pragma unroll
-            for (int k = 0; k < 4; k++) bb[k] = fd[k] + (fg[k] + hf[k]);
-            const float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
-            // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring); the thread writes its own quad as soon as a pixel is done
-            float* const pl = lab + (2 * lqy + 1) * LPS + 2 * lqx + 1;
+            for (int k = 0; k < 4; k++) bb[q][k] = fd[k] + (fg[k] + hf[k]);
+            gg[q][0] = wgr.v[1][1]; gg[q][1] = g1_c; gg[q][2] = g2_c; gg[q][3] = wgb.v[1][1];
+        };
+        // Lab pixel (py,px) of the region lives at [py+1][px+1] (guard ring); the thread writes its own quad as soon as a pixel is done
+        auto lab_px = [&](const int q, const int k) {
+            const Quad& c = qc[q];
+            float (&rgbc)[4][3] = dir == 0 ? rgbh[q] : rgbv[q];
+            float* const pl = lab + (2 * c.lqy + 1) * LPS + 2 * c.lqx + 1;
+            float L, A, Bq;
+            homog_lab<LAB>(lt, p.lablut, rr[q][k], gg[q][k], bb[q][k], p.wb, M, HDR, L, A, Bq);
+            float* const o = pl + (k >> 1) * LPS + (k & 1);
+            o[0] = L; o[LPR * LPS] = A; o[2 * LPR * LPS] = Bq;
+            rgbc[k][0] = rr[q][k]; rgbc[k][1] = gg[q][k]; rgbc[k][2] = bb[q][k];
+        };
+        if constexpr (QPT == 1) {
+            if (qc[0].active) {
+                candidate(0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    lab_px(0, k);
+#ifndef AHD_NO_SB
+                    __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
+#endif
+                }
+            }
+        } else {
+            // several quads per thread: the k-th pixels of all of them are evaluated together -- independent gather + interpolation chains between scheduling barriers
+#pragma unroll
+            for (int q = 0; q < QPT; q++) if (qc[q].active) candidate(q);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float L, A, Bq;
-                homog_lab<LAB>(lt, p.lablut, rr[k], gg[k], bb[k], p.wb, M, HDR, L, A, Bq);
-                float* const o = pl + (k >> 1) * LPS + (k & 1);
-                o[0] = L; o[LPR * LPS] = A; o[2 * LPR * LPS] = Bq;
-                rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
+#pragma unroll
+                for (int q = 0; q < QPT; q++) if (qc[q].active) lab_px(q, k);
 #ifndef AHD_NO_SB
-                __builtin_amdgcn_sched_barrier(0);   // keep the four Lab evaluations from interleaving (register pressure)
+                __builtin_amdgcn_sched_barrier(0);
 #endif
             }
         }
@@ -405,7 +445,12 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         AHD_STAMP(dir == 0 ? 6 : 10);
 
         // ---- P3: homogeneity vote (pyx:22-58), all four pixels of the quad from one 4x4 Lab window
-        if (active) {
+#pragma unroll
+        for (int q = 0; q < QPT; q++) {
+            const Quad& c = qc[q];
+            if (!c.active) continue;
+            const int lqy = c.lqy, lqx = c.lqx;
+            const bool at_top = c.at_top, at_bot = c.at_bot, at_left = c.at_left, at_right = c.at_right;
             // the upper pixel pair votes from window rows 0-2, then row 3 arrives (in row 0's registers) for the lower pair: 36 instead of 48 window registers
             float wl[4][4], wa[4][4], wq[4][4];
             int cnt[4];
@@ -432,14 +477,14 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc); }
 #endif
             if (dir == 0) {
-                hvotes = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
+                hvotes[q] = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
             } else {
                 // the mosaic planes are dead (the barrier above closed the last P2): the packed map h | v << 8 goes over them
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    int yy = vmy + (k >> 1), xx = vmx + (k & 1);
+                    int yy = c.vmy + (k >> 1), xx = c.vmx + (k & 1);
                     if (yy >= 0 && yy < MPR && xx >= 0 && xx < 2 * TQX + 2)
-                        vmap[yy * MPS + xx] = (unsigned short)(((hvotes >> (4 * k)) & 15u) | ((unsigned)cnt[k] << 8));
+                        vmap[yy * MPS + xx] = (unsigned short)(((hvotes[q] >> (4 * k)) & 15u) | ((unsigned)cnt[k] << 8));
                 }
             }
         }
@@ -456,34 +501,37 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     AHD_STAMP(12);
 
     // ---- P4: 3x3 box (cv2.blur, REFLECT_101; integer sums order like the float means), select, store
-    if (inner) {
+#pragma unroll
+    for (int q = 0; q < QPT; q++) {
+        const Quad& c = qc[q];
+        if (!c.inner) continue;
         // 4x4 packed votes around the quad: rows vmy-1..vmy+2, cols vmx-1..vmx+2 (vmx-1 is even)
         unsigned int s012[4], s123[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const unsigned int* wp = reinterpret_cast<const unsigned int*>(&vmap[(vmy - 1 + r) * MPS + vmx - 1]);   // 4-byte aligned
+            const unsigned int* wp = reinterpret_cast<const unsigned int*>(&vmap[(c.vmy - 1 + r) * MPS + c.vmx - 1]);   // 4-byte aligned
             uint2 wv = make_uint2(wp[0], wp[1]);
-            if (at_left) wv.x = (wv.x & 0xFFFF0000u) | (wv.y & 0xFFFFu);          // col -1 -> col 1
-            if (at_right) wv.y = (wv.y & 0xFFFFu) | (wv.x & 0xFFFF0000u);         // col W -> col W-2
-            unsigned int a = wv.x & 0xFFFFu, b = wv.x >> 16, c = wv.y & 0xFFFFu, d = wv.y >> 16;
-            s012[r] = a + b + c; s123[r] = b + c + d;
+            if (c.at_left) wv.x = (wv.x & 0xFFFF0000u) | (wv.y & 0xFFFFu);          // col -1 -> col 1
+            if (c.at_right) wv.y = (wv.y & 0xFFFFu) | (wv.x & 0xFFFF0000u);         // col W -> col W-2
+            unsigned int a = wv.x & 0xFFFFu, b = wv.x >> 16, cc = wv.y & 0xFFFFu, d = wv.y >> 16;
+            s012[r] = a + b + cc; s123[r] = b + cc + d;
         }
-        if (at_top) { s012[0] = s012[2]; s123[0] = s123[2]; }                     // row -1 -> row 1
-        if (at_bot) { s012[3] = s012[1]; s123[3] = s123[1]; }                     // row H -> row H-2
+        if (c.at_top) { s012[0] = s012[2]; s123[0] = s123[2]; }                     // row -1 -> row 1
+        if (c.at_bot) { s012[3] = s012[1]; s123[3] = s123[1]; }                     // row H -> row H-2
         float px[4][3];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int dy = k >> 1, dx = k & 1;
-            unsigned int s = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
-            unsigned int sh = s & 0xFFu, sv = s >> 8;
-            float c = sh < sv ? 1.0f : 0.0f, nc = 1.0f - c;            // ahd.py:139-145, literally
-            px[k][0] = rgbh[k][0] * c + rgbv[k][0] * nc;
-            px[k][1] = rgbh[k][1] * c + rgbv[k][1] * nc;
-            px[k][2] = rgbh[k][2] * c + rgbv[k][2] * nc;
+            unsigned int sm = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
+            unsigned int sh = sm & 0xFFu, sv = sm >> 8;
+            float cf = sh < sv ? 1.0f : 0.0f, nc = 1.0f - cf;            // ahd.py:139-145, literally
+            px[k][0] = rgbh[q][k][0] * cf + rgbv[q][k][0] * nc;
+            px[k][1] = rgbh[q][k][1] * cf + rgbv[q][k][1] * nc;
+            px[k][2] = rgbh[q][k][2] * cf + rgbv[q][k][2] * nc;
             if (TAIL) colour_tail(p.tail, M, px[k][0], px[k][1], px[k][2]);
         }
         // two rows of three 8-byte stores instead of twelve dword stores; uniform tile origin + tile-local 32-bit offset (inner: lqy, lqx >= 1)
-        store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, lqy - 1, lqx - 1, px);
+        store_quad_direct(p.out + ((size_t)(2 * tq0y) * W + 2 * tq0x) * 3, W, c.lqy - 1, c.lqx - 1, px);
     }
     AHD_STAMP(13);             // P4 done (stores issued)
 }
