@@ -12,11 +12,12 @@
 //   then, for the horizontal and the vertical candidate in turn (one code path, unrolled twice):
 //   P2  one thread per quad (halo 1 quad): high-pass of green, photosite-aware resampling of
 //       R and B, second white balance + float64 CCM + Lab, all in registers; Lab -> LDS
-//   P3  homogeneity vote from a 4x4 Lab window per quad (8-byte LDS reads, edge cells by select);
-//       the Lab buffer lies over the by then dead mosaic and horizontal g/D planes
+//   P3  homogeneity vote from a 4x4 Lab window per quad (8-byte LDS reads, edge cells by select), in two row pieces;
+//       the Lab buffer is its own LDS section (round 3), the vertical green planes are built into the plane buffer meanwhile
 //   finally
 //   P4  3x3 box of the packed votes (integer), H/V selection (both candidates still in registers), optional colour tail, store.
-// 92-93 VGPRs; 20.6 KB of LDS with the Lab grid of mode 1 (read from L2), 30.6 KB with the closed-form tables of mode 0: five workgroups per CU.
+// 71 VGPRs; 25.5 KB of LDS with the Lab grid of mode 1 (read from L2): six workgroups per CU (round 2: 92 VGPRs, 20.6 KB, five).
+// -DAHD_TQX / -DAHD_TQY / -DAHD_QPT build the other tile shapes and the two-quads-per-thread form measured in DESIGN.md 7.0 (c).
 // Image-border rules (three of them coexist) are applied at true image edges only.
 #include "demosaic_common.h"
 #include "kernels.h"
