@@ -34,6 +34,43 @@ def test_model_fields_match_reference_fixture():
         assert np.allclose(m.get_distorted(m.estimate_undistorted(r)), r, atol=2e-5)
 
 
+def test_lens_fields_in_row_blocks_on_the_host_team_are_the_serial_bits(monkeypatch):
+    """pysp_amd/_hostpar.py: the lens fields are evaluated in row blocks on a thread team.  Same bytes as the serial (= reference) expressions:
+    every model, Python-float and float64 coefficients (the float64 detour widens every block at the same Newton step), ragged block sizes, a field
+    whose inversion does not converge (the global stopping rule), and the fixture again with the team forced on at the fixture's small size."""
+    from pysp_amd import _hostpar
+    from pysp_amd.corr_ca.model import generic
+    cases = [("poly3_pyfloat", (0.004,)), ("poly5_f64", (1.5e-3, -4e-4)), ("poly5_pyfloat", (2e-3, 1e-4)), ("ptlens_f64", (2e-4, -6e-4, 3e-4)),
+             ("poly3_pyfloat", (0.9,))]
+    for shape in ((262, 390), (98, 1030)):
+        probe = np.zeros(shape, np.float32)
+        for key, coefs in cases:
+            monkeypatch.setenv("PYSP_HOST_THREADS", "1")
+            m = _models()[key](coefs)
+            u0, d0 = m.get_undistorted_quadrant(probe), m.get_distorted_quadrant(probe)
+            r = generic.get_empty_radius_field(probe).reshape(-1)
+            e0 = m.estimate_undistorted(r)
+            for team in (2, 5, 7):
+                monkeypatch.setenv("PYSP_HOST_THREADS", str(team))
+                monkeypatch.setattr(_hostpar, "MIN_PARALLEL_ELEMS", 16)
+                u1, d1, e1 = m.get_undistorted_quadrant(probe), m.get_distorted_quadrant(probe), m.estimate_undistorted(r)
+                monkeypatch.setattr(_hostpar, "MIN_PARALLEL_ELEMS", 1 << 18)
+                assert u1.dtype == u0.dtype and u1.tobytes() == u0.tobytes(), (key, shape, team)
+                assert d1.dtype == d0.dtype and d1.tobytes() == d0.tobytes(), (key, shape, team)
+                assert e1.dtype == e0.dtype and e1.shape == e0.shape and e1.tobytes() == e0.tobytes(), (key, shape, team)
+    monkeypatch.setenv("PYSP_HOST_THREADS", "3")
+    monkeypatch.setattr(_hostpar, "MIN_PARALLEL_ELEMS", 16)
+    d, meta = load_golden("g12_ca_removal")
+    probe = np.zeros(d["bayer"].shape, np.float32)
+    for key, coefs in meta["models"].items():
+        m = _models()[key](coefs)
+        assert np.array_equal(m.get_undistorted_quadrant(probe), d[key + "_undist"]) and np.array_equal(m.get_distorted_quadrant(probe), d[key + "_dist"]), key
+    assert [s.stop - s.start for s in _hostpar.blocks(10, 4)] == [2, 3, 2, 3] and _hostpar.blocks(3, 8) == [slice(0, 1), slice(1, 2), slice(2, 3)]
+    assert _hostpar.pmap(lambda v: v * v, [1, 2, 3]) == [1, 4, 9]
+    with pytest.raises(ZeroDivisionError):
+        _hostpar.pmap(lambda v: 1 // v, [1, 0, 2])
+
+
 def test_radius_and_coord_fields():
     from pysp_amd.corr_ca.model.generic import get_empty_coord_field, get_empty_radius_field, mirror_quadrant
     img = np.zeros((6, 8), np.float32)
