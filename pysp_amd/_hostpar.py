@@ -64,3 +64,13 @@ def pmap(fn: Callable, parts: Sequence) -> list:
     if n <= 1:
         return [fn(p) for p in parts]
     return list(_pool(team()).map(fn, parts))
+
+
+def copy_into(dst: np.ndarray, src) -> np.ndarray:
+    """np.copyto(dst, src) (same shape; casting as np.copyto's default), large arrays in row blocks on the host team; returns dst."""
+    src = np.asarray(src)
+    if dst.ndim == 0 or dst.size < MIN_PARALLEL_ELEMS or team() == 1 or src.shape != dst.shape:
+        np.copyto(dst, src)
+        return dst
+    pmap(lambda sl: np.copyto(dst[sl], src[sl]), blocks(dst.shape[0], team()))
+    return dst

@@ -271,8 +271,21 @@ def empty_f32(shape) -> np.ndarray:
     return _hostpool.empty(shape, np.float32)
 
 
+def empty(shape, dtype) -> np.ndarray:
+    """np.empty(shape, dtype) for results the library writes: large ones come from the page-locked pool (no first-touch page faults on reuse)."""
+    from . import _hostpool
+    return _hostpool.empty(shape, np.dtype(dtype))
+
+
 def f32c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def f32_private(a) -> np.ndarray:
+    """A private C-contiguous float32 copy of `a` (np.array(a, float32, order="C", copy=True)) in a pooled buffer, copied on the host team."""
+    from . import _hostpar
+    a = np.asarray(a)
+    return _hostpar.copy_into(empty_f32(a.shape), a)
 
 
 def wb3(wb) -> "ctypes.Array":

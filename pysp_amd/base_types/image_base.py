@@ -64,7 +64,7 @@ class RawDemosaicData:
             _lib.check(_lib.lib().pysp_wb_scale_dev(self._dev.context.handle, self._dev.ptr, self._dev.size // 3, _lib.wb3(self._wb_coeff), int(undo), dst.ptr))
             return dst
         src = _lib.f32c(self.image)
-        dst = np.empty_like(src)
+        dst = _lib.empty_f32(src.shape)
         _lib.check(_lib.lib().pysp_wb_scale_f32(_lib.default_context().handle, _lib.ptr(src), src.size // 3,
                                                 _lib.wb3(self._wb_coeff), int(undo), _lib.ptr(dst)))
         return dst

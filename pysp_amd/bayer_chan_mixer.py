@@ -11,7 +11,7 @@ def bayer_to_rgbg(rgbg: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray,
     if rgbg.ndim != 2:
         raise ValueError("Bayer mosaic must be 2-D")
     H, W = rgbg.shape
-    outs = [np.empty((H // 2, W // 2), np.float32) for _ in range(4)]
+    outs = [_lib.empty_f32((H // 2, W // 2)) for _ in range(4)]
     ctx = _lib.default_context()
     if rgbg.dtype == np.uint16:
         src = np.ascontiguousarray(rgbg)
@@ -30,6 +30,6 @@ def rgbg_to_bayer(r: np.ndarray, g1, b, g2) -> np.ndarray:
     if any(p.shape != r.shape for p in planes):
         raise ValueError("quarter planes must share one shape")
     h, w = r.shape
-    out = np.empty((2 * h, 2 * w), np.float32)
+    out = _lib.empty_f32((2 * h, 2 * w))
     _lib.check(_lib.lib().pysp_rgbg_to_bayer_f32(_lib.default_context().handle, *[_lib.ptr(p) for p in planes], h, w, _lib.ptr(out)))
     return out

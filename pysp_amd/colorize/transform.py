@@ -63,7 +63,7 @@ def cam_to_clean_xyz(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, pcs_colors
                      clip_highlights: bool = True) -> np.ndarray:
     """transform.py:55-74: detinted working RGB, then that space's RGB->XYZ (second float64 dot)."""
     work = cam_to_rgb_norm(rgb, cam_xyz_matrix, pcs_colorspace, clip_highlights)
-    out = np.empty_like(work)
+    out = _lib.empty_f32(work.shape)
     _lib.check(_lib.lib().pysp_cam_to_rgb_f32(_lib.default_context().handle, _lib.ptr(work), work.size // 3,
                                               _lib.mat9(pcs_colorspace.mat_to_xyz()), 0, _lib.ptr(out)))
     return out

@@ -33,7 +33,7 @@ def remove_ca_from_raw(raw, lens_model_r: Optional[CaCorrectionModel], lens_mode
     if lens_model_b is not None and not isinstance(lens_model_b, ReversibleModelMixin):
         raise ValueError("Blue lens model is not reversible so green cannot be re-aligned to remove error. Use a reversible model and try again.")
 
-    bayer = np.array(raw.sensor_scaled, dtype=np.float32, order="C")   # private copy, corrected in place by the library
+    bayer = _lib.f32_private(raw.sensor_scaled)   # private copy, corrected in place by the library
     if bayer.ndim != 2 or bayer.shape[0] % 2 or bayer.shape[1] % 2:
         raise ValueError("expected a Bayer mosaic with even dimensions")
     H, W = bayer.shape

@@ -23,7 +23,7 @@ def resample_g_to_full_resolution(g1: np.ndarray, g2: np.ndarray, use_bilinear_w
     a, b = _plane(g1), _plane(g2)
     assert a.shape == b.shape
     h, w = a.shape
-    out = np.empty((2 * h, 2 * w), np.float32)
+    out = _lib.empty_f32((2 * h, 2 * w))
     _lib.check(_lib.lib().pysp_resample_g_f32(_lib.default_context().handle, _lib.ptr(a), _lib.ptr(b), h, w, int(bool(use_bilinear_weighting)), _lib.ptr(out)))
     return out
 
@@ -41,7 +41,7 @@ def resample_channel(subpixel: np.ndarray, g_at_subpixel: np.ndarray, g_hf_pass:
     h, w = s.shape
     if hf.shape != (2 * h, 2 * w):
         raise ValueError("g_hf_pass must be the full-resolution plane")
-    out = np.empty((2 * h, 2 * w), np.float32)
+    out = _lib.empty_f32((2 * h, 2 * w))
     _lib.check(_lib.lib().pysp_resample_channel_f32(_lib.default_context().handle, _lib.ptr(s), _lib.ptr(g), _lib.ptr(hf), None, h, w,
                                                     _pos(bayer_position), _lib.ptr(out)))
     return out
@@ -52,7 +52,7 @@ def _resample_from_full(chan: np.ndarray, g_upscaled: np.ndarray, pos: int) -> n
     h, w = c.shape
     if g.shape != (2 * h, 2 * w):
         raise ValueError("g_upscaled must be twice the channel's size")
-    out = np.empty((2 * h, 2 * w), np.float32)
+    out = _lib.empty_f32((2 * h, 2 * w))
     _lib.check(_lib.lib().pysp_resample_channel_f32(_lib.default_context().handle, _lib.ptr(c), None, None, _lib.ptr(g), h, w, pos, _lib.ptr(out)))
     return out
 

@@ -6,7 +6,7 @@ from .. import _lib
 
 def _table(seed, kr0, kr1, kr2, kr3, kt0, kt1, width, height, cx, cy, scale) -> np.ndarray:
     width, height = int(width), int(height)
-    out = np.empty((height, width, 2), np.float32)
+    out = _lib.empty_f32((height, width, 2))
     sp = None
     if seed is not None:
         if seed.dtype != np.float32 or seed.shape != (height, width, 2):

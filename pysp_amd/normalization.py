@@ -18,7 +18,7 @@ def bayer_normalize(rgbg: np.ndarray, chan_black, chan_sat) -> np.ndarray:
     H, W = src.shape
     black = (ctypes.c_float * 4)(*[float(chan_black[i]) for i in range(4)])
     sat = (ctypes.c_float * 4)(*[float(chan_sat[i]) for i in range(4)])
-    out = np.empty((H, W), np.float32)
+    out = _lib.empty_f32((H, W))
     _lib.check(_lib.lib().pysp_bayer_normalize_u16(_lib.default_context().handle, _lib.ptr(src), H, W, black, sat, _lib.ptr(out)))
     return out
 
@@ -34,7 +34,7 @@ def raw_to_rgb(rgbg: np.ndarray, chan_black, chan_sat, cam_wb, quality: int = _l
     H, W = src.shape
     black = (ctypes.c_float * 4)(*[float(chan_black[i]) for i in range(4)])
     sat = (ctypes.c_float * 4)(*[float(chan_sat[i]) for i in range(4)])
-    out = np.empty((H, W, 3), np.float32)
+    out = _lib.empty_f32((H, W, 3))
     _lib.check(_lib.lib().pysp_pipeline_u16_f32(_lib.default_context().handle, _lib.ptr(src), H, W, black, sat,
                                                 _lib.wb3(cam_wb.get_reciprocal_multipliers()), _lib.mat9(final_matrix(cam_wb.get_matrix())),
                                                 int(quality), 0, int(postprocess_steps), int(tail), _lib.ptr(out)))

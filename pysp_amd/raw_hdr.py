@@ -45,8 +45,8 @@ def fuse_exposures_to_raw(in_exposures: List[RawRggbBayerData], target_ev: Optio
     off32 = np.array(ev_offsets, dtype=np.float32)
     kmax = int(np.argmax(ev_offsets))
 
-    fused = np.empty((H, W), np.float32)
-    count = np.empty((H, W), np.int32)
+    fused = _lib.empty_f32((H, W))
+    count = _lib.empty((H, W), np.int32)
     ptrs = (ctypes.c_void_p * K)(*[f.ctypes.data for f in frames])
     _lib.check(_lib.lib().pysp_fuse_raw_f32(_lib.default_context().handle, ptrs, K, H, W,
                                             off32.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
@@ -74,7 +74,7 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
     shape = in_exposures[0].image.shape
     if any(e._wb_normalized for e in valid):
         raise NotImplementedError("normalised white balance (wb_norm=True) is not produced by any demosaic path and is not fused on the GPU")
-    imgs = [np.array(e.image, dtype=np.float32, order="C", copy=True) for e in valid]
+    imgs = [_lib.f32_private(e.image) for e in valid]          # private copies: the library writes the undo/apply round trip back into them
     if any(a.shape != shape for a in imgs):
         raise ValueError("all exposures must share one shape")
     coeff = np.ascontiguousarray(np.stack([np.asarray(e._wb_coeff, dtype=np.float32)[:3] for e in valid]))
@@ -84,8 +84,8 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
     kmax = max(k for k, off in enumerate(ev_offsets) if off == np.max(ev_offsets))        # :67-68, last match wins
     from .colorize.transform import final_matrix
     M = _lib.mat9(final_matrix(in_exposures[0].mat_xyz))
-    fused = np.empty(shape, np.float32)
-    count = np.empty(shape, np.int32)
+    fused = _lib.empty_f32(shape)
+    count = _lib.empty(shape, np.int32)
     ptrs = (ctypes.c_void_p * K)(*[a.ctypes.data for a in imgs])
     fp = ctypes.POINTER(ctypes.c_float)
     _lib.check(_lib.lib().pysp_fuse_rgb_f32(_lib.default_context().handle, ptrs, K, ctypes.c_size_t(imgs[0].size // 3),
