@@ -198,6 +198,9 @@ int pysp_fuse_raw_dev(pysp_ctx *ctx, const float *const *d_frames, int K, int H,
  * write_back != 0 stores into frames[k] the wb_undo/wb_apply round-tripped image the reference leaves
  * in exposure.image (:56,:65).  out: (npx,3) float32, count: (npx,3) int32. */
 int pysp_fuse_rgb_f32(pysp_ctx *ctx, float *const *frames, int K, size_t npx, const float *coeff, const int *applied, const float *ev_off, const float *bias, int kmax, const double *M, float *out, int32_t *count, int write_back);
+/* The same on device buffers (exposures that a demosaic left in HBM are fused there): d_frames_rt is NULL or K pointers, each NULL or a buffer
+ * (it may be d_frames[k] itself) that receives exposure k's wb_undo/wb_apply round trip (raw_hdr.py:56,:65).  Enqueued on the context's stream. */
+int pysp_fuse_rgb_dev(pysp_ctx *ctx, const float *const *d_frames, float *const *d_frames_rt, int K, size_t npx, const float *coeff, const int *applied, const float *ev_off, const float *bias, int kmax, const double *M, float *d_out, int32_t *d_count);
 
 /* ---- DNG WarpRectilinear --------------------------------------------------------------------
  * dng_warp_corr/dng_warp_rectilinear_coords.pyx:67-80 compute_remapping_table and :82-96

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "pysp_fuse_raw_f32": (_int, [_vp, ctypes.POINTER(_vp), _int, _int, _int, _f32p, _f32p, _int, _vp, _vp]),
     "pysp_fuse_raw_dev": (_int, [_vp, ctypes.POINTER(_vp), _int, _int, _int, _f32p, _f32p, _int, _vp, _vp]),
     "pysp_fuse_rgb_f32": (_int, [_vp, ctypes.POINTER(_vp), _int, _sz, _f32p, ctypes.POINTER(_int), _f32p, _f32p, _int, _f64p, _vp, _vp, _int]),
+    "pysp_fuse_rgb_dev": (_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _int, _sz, _f32p, ctypes.POINTER(_int), _f32p, _f32p, _int, _f64p, _vp, _vp]),
     "pysp_warp_table_f32": (_int, [_vp, _flt, _flt, _flt, _flt, _flt, _flt, _int, _int, _flt, _flt, _flt, _vp, _vp]),
     "pysp_warp_rectilinear_f32": (_int, [_vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt]),
     "pysp_warp_rectilinear_prior_f32": (_int, [_vp, _vp, _int, _int, _f64p, _int, _dbl, _dbl, _flt, _vp]),

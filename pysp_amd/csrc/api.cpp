@@ -804,6 +804,21 @@ int pysp_fuse_rgb_f32(pysp_ctx* ctx, float* const* frames, int K, size_t npx, co
     return pysp_ctx_sync(ctx);
 }
 
+int pysp_fuse_rgb_dev(pysp_ctx* ctx, const float* const* d_frames, float* const* d_frames_rt, int K, size_t npx, const float* coeff, const int* applied,
+                      const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count) {
+    CTX_ENTER(ctx);
+    if (!d_frames || !coeff || !applied || !ev_off || !bias || !d_out || !d_count) return fail(PYSP_EBADARG, "fuse_rgb: null pointer");
+    if (K < 1 || K > 12 || kmax < 0 || kmax >= K || npx == 0) return fail(PYSP_EBADARG, "fuse_rgb: 1..12 exposures supported (got %d)", K);
+    for (int k = 0; k < K; k++)
+        if (!d_frames[k]) return fail(PYSP_EBADARG, "fuse_rgb: null frame %d", k);
+    ctx->tic();
+    ctx->tl.begin(ctx->stream, "k_fuse_rgb");
+    LAUNCH_TRY(launch_fuse_rgb(ctx->stream, d_frames, d_frames_rt, K, npx, coeff, applied, ev_off, bias, kmax, M, d_out, d_count));
+    ctx->tl.end(ctx->stream);
+    ctx->toc();
+    return PYSP_OK;
+}
+
 // ---- WarpRectilinear ----------------------------------------------------------------------------------
 int pysp_warp_table_f32(pysp_ctx* ctx, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height, float cx_norm,
                         float cy_norm, float scale, const float* seed, float* table) {

@@ -71,28 +71,43 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
         return None
     K = len(valid)
     target_ev, ev_offsets = _ev_offsets([e.current_ev for e in valid], target_ev)
-    shape = in_exposures[0].image.shape
+    first = in_exposures[0]
+    shape = tuple(first._dev.shape) if (first._dev is not None and first._dev.on_device) else tuple(first.image.shape)     # (no download just to ask)
     if any(e._wb_normalized for e in valid):
         raise NotImplementedError("normalised white balance (wb_norm=True) is not produced by any demosaic path and is not fused on the GPU")
-    imgs = [_lib.f32_private(e.image) for e in valid]          # private copies: the library writes the undo/apply round trip back into them
-    if any(a.shape != shape for a in imgs):
-        raise ValueError("all exposures must share one shape")
     coeff = np.ascontiguousarray(np.stack([np.asarray(e._wb_coeff, dtype=np.float32)[:3] for e in valid]))
     applied = (ctypes.c_int * K)(*[int(bool(e._wb_applied)) for e in valid])
     bias = np.array([1.6 ** (-0.1 * off) for off in ev_offsets]).astype(np.float32)          # :60-61
     off32 = np.array(ev_offsets, dtype=np.float32)
     kmax = max(k for k, off in enumerate(ev_offsets) if off == np.max(ev_offsets))        # :67-68, last match wins
     from .colorize.transform import final_matrix
+    from .device_array import DeviceArray, as_device, lazy_enabled
     M = _lib.mat9(final_matrix(in_exposures[0].mat_xyz))
-    fused = _lib.empty_f32(shape)
-    count = _lib.empty(shape, np.int32)
-    ptrs = (ctypes.c_void_p * K)(*[a.ctypes.data for a in imgs])
+    # Device resident: an exposure that a demosaic left in HBM is fused there (no download + private copy + upload per exposure); host images are
+    # uploaded once, straight from the caller's arrays, which stay untouched -- the round trip lands in new buffers, as the reference's
+    # wb_undo() / wb_apply() rebind exposure.image to new arrays.
+    ctx = next((e._dev.context for e in valid if e._dev is not None and e._dev.on_device), None) or _lib.default_context()
+    d_in = []
+    for e in valid:
+        src = e._dev if (e._dev is not None and e._dev.on_device) else e._img
+        if tuple(src.shape) != tuple(shape):
+            raise ValueError("all exposures must share one shape")
+        d_in.append(as_device(src, ctx))
+    d_rt = [DeviceArray(ctx, shape) for _ in valid]
+    d_out, d_cnt = DeviceArray(ctx, shape), DeviceArray(ctx, shape)          # the counts are int32 in a buffer of the same size
+    vpp = ctypes.c_void_p * K
     fp = ctypes.POINTER(ctypes.c_float)
-    _lib.check(_lib.lib().pysp_fuse_rgb_f32(_lib.default_context().handle, ptrs, K, ctypes.c_size_t(imgs[0].size // 3),
-                                            coeff.ctypes.data_as(fp), applied, off32.ctypes.data_as(fp), bias.ctypes.data_as(fp),
-                                            kmax, M, _lib.ptr(fused), _lib.ptr(count), 1))
-    for e, a in zip(valid, imgs):           # the state wb_undo(); wb_apply() leaves behind
-        e.image = a
+    npx = int(np.prod(shape, dtype=np.int64)) // 3
+    with ctx.lock:
+        _lib.check(_lib.lib().pysp_fuse_rgb_dev(ctx.handle, vpp(*[d.ptr.value for d in d_in]), vpp(*[d.ptr.value for d in d_rt]), K, ctypes.c_size_t(npx),
+                                                coeff.ctypes.data_as(fp), applied, off32.ctypes.data_as(fp), bias.ctypes.data_as(fp), kmax, M, d_out.ptr, d_cnt.ptr))
+        count = _lib.empty(shape, np.int32)
+        _lib.check(_lib.lib().pysp_dev_download(ctx.handle, _lib.ptr(count), d_cnt.ptr, ctypes.c_size_t(count.nbytes)))      # waits for the kernel: the uploads' sources may go
+    del d_in, d_cnt
+    lazy = lazy_enabled()
+    for e, rt in zip(valid, d_rt):           # the state wb_undo(); wb_apply() leaves behind
+        e.image = rt if lazy else rt.numpy()
         e._wb_applied = True
         e._wb_normalized = False
+    fused = d_out if lazy else d_out.numpy()
     return (fused, count)

@@ -322,8 +322,35 @@ def test_fuse_from_debayer_golden_and_oracle(orc, wbobj):
         a[:5, :5] = 0.0
     evs = [8.0, 9.0, 10.0, 11.0, 11.0]                # two exposures share the maximum offset: the last one wins
     fused, cnt = fuse_exposures_from_debayer([mk(a, ev) for a, ev in zip(imgs, evs)])
-    ref, refc, _ = orc.fuse_rgb(imgs, evs, 1.0 / d["mult"], M)
+    ref, refc, left = orc.fuse_rgb(imgs, evs, 1.0 / d["mult"], M)
     assert np.array_equal(fused, ref) and np.array_equal(cnt, refc)
+    # round 3: the fusion is device resident.  Exposures whose image is still in HBM (as a demosaic leaves it) are fused there, host images are
+    # uploaded straight from the caller's arrays (which stay untouched), results and round-tripped images stay lazy until read; PYSP_EAGER
+    # semantics (set_lazy(False)) hand out plain ndarrays.  Same bits every way.
+    import pysp_amd
+    from pysp_amd.device_array import DeviceArray
+    from pysp_amd import _lib as _plib
+    ctx = _plib.default_context()
+    originals = [a.copy() for a in imgs]
+    was = pysp_amd.lazy_enabled()
+    try:
+        for lazy in (True, False):
+            pysp_amd.set_lazy(lazy)
+            exps = [mk(a, ev) for a, ev in zip(imgs, evs)]
+            for k in (0, 2, 4):                           # some exposures resident, some on the host, one not white balanced
+                exps[k].image = DeviceArray.from_host(ctx, imgs[k])
+            exps[1]._wb_applied = False
+            host_in = exps[1]._img
+            fused, cnt = fuse_exposures_from_debayer(exps)
+            assert isinstance(fused, DeviceArray if lazy else np.ndarray) and isinstance(cnt, np.ndarray) and cnt.dtype == np.int32
+            ref1, refc1, left1 = orc.fuse_rgb(imgs, evs, 1.0 / d["mult"], M, applied=[True, False, True, True, True])
+            assert np.array_equal(np.asarray(fused), ref1) and np.array_equal(cnt, refc1)
+            assert np.array_equal(host_in, imgs[1]) and all(np.array_equal(a, o) for a, o in zip(imgs, originals))      # inputs untouched
+            for e, a in zip(exps, left1):
+                assert e._wb_applied and not e._wb_normalized
+                assert (e._dev is not None) == lazy and np.array_equal(e.image, a) and isinstance(e.image, np.ndarray)
+    finally:
+        pysp_amd.set_lazy(was)
 
 
 # ---- WarpRectilinear ------------------------------------------------------------------------------------------------------
