@@ -5,6 +5,7 @@ per block on a thread each gives the same bits, sooner.  PYSP_HOST_THREADS overr
 from __future__ import annotations
 
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, List, Optional, Sequence
 
@@ -13,6 +14,7 @@ import numpy as np
 _POOL: Optional[ThreadPoolExecutor] = None
 _POOL_N = 0
 _POOL_PID = 0                           # a forked child inherits the object but not its threads: it builds its own
+_POOL_LOCK = threading.Lock()
 MIN_PARALLEL_ELEMS = 1 << 18          # below this the serial pass is faster than the hand-off
 
 
@@ -44,11 +46,12 @@ def team() -> int:
 def _pool(n: int) -> ThreadPoolExecutor:
     global _POOL, _POOL_N, _POOL_PID
     pid = os.getpid()
-    if _POOL is None or _POOL_N != n or _POOL_PID != pid:
-        if _POOL is not None and _POOL_PID == pid:
-            _POOL.shutdown(wait=False)
-        _POOL, _POOL_N, _POOL_PID = ThreadPoolExecutor(max_workers=n, thread_name_prefix="pysp-host"), n, pid
-    return _POOL
+    with _POOL_LOCK:
+        if _POOL is None or _POOL_N != n or _POOL_PID != pid:
+            if _POOL is not None and _POOL_PID == pid:
+                _POOL.shutdown(wait=False)          # tasks already queued still run; callers holding the old pool finish on it
+            _POOL, _POOL_N, _POOL_PID = ThreadPoolExecutor(max_workers=n, thread_name_prefix="pysp-host"), n, pid
+        return _POOL
 
 
 def blocks(n_items: int, n_blocks: int) -> List[slice]:
