@@ -19,6 +19,8 @@
 // 71 VGPRs; 25.5 KB of LDS with the Lab grid of mode 1 (read from L2): six workgroups per CU (round 2: 92 VGPRs, 20.6 KB, five).
 // -DAHD_TQX / -DAHD_TQY / -DAHD_QPT build the other tile shapes and the two-quads-per-thread form measured in DESIGN.md 7.0 (c).
 // Image-border rules (three of them coexist) are applied at true image edges only.
+#include <type_traits>
+
 #include "demosaic_common.h"
 #include "kernels.h"
 
@@ -214,6 +216,45 @@ DEVI void vote_quad_literal(const float wl[4][4], const float wa[4][4], const fl
     }
 }
 
+// The literal vote once more, for the workgroups of the HDR instance that really hold a non-finite luma (rare): every cell is read from LDS where it is used, one pixel
+// per trip of a rolled loop, so that this path adds next to nothing to the registers of the kernel's fast path (with the 4x4 windows of vote_quad_literal in registers
+// the two forms behind one uniform branch came to 87 VGPRs, five workgroups per CU instead of six).  Same arithmetic, cell for cell, as vote_quad_literal;
+// window cell (Y, X) of an image-edge quad takes the duplicated edge pixel (BORDER_REFLECT, ahd.py:64) by clamping its coordinates.  Returns the four counts, 4 bits each.
+template <int DIR>
+DEVI unsigned vote_quad_literal_lds(const float* lab, int lqy, int lqx, bool at_top, bool at_bot, bool at_left, bool at_right) {
+    const float* const pL = lab + (2 * lqy) * LPS + 2 * lqx;
+    auto cell = [&](int Y, int X) -> const float* {
+        Y = (at_top && Y == 0) ? 1 : ((at_bot && Y == 3) ? 2 : Y);
+        X = (at_left && X == 0) ? 1 : ((at_right && X == 3) ? 2 : X);
+        return pL + Y * LPS + X;
+    };
+    unsigned packed = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
+        const float* pc = cell(cy, cx);
+        const float* p1 = cell(n1y, n1x);
+        const float* p2 = cell(n2y, n2x);
+        const float rl = pc[0], ra = pc[LPR * LPS], rb = pc[2 * LPR * LPS];
+        const float e1 = fabsf(rl - p1[0]), e2 = fabsf(rl - p2[0]);
+        const float da1 = ra - p1[LPR * LPS], db1 = rb - p1[2 * LPR * LPS], da2 = ra - p2[LPR * LPS], db2 = rb - p2[2 * LPR * LPS];
+        const float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
+        const float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
+        int c = 0;
+#pragma unroll 1
+        for (int wy = 0; wy < 3; wy++)
+#pragma unroll 1
+            for (int wx = 0; wx < 3; wx++) {
+                const float* pw = cell(dy + wy, dx + wx);
+                const float da = pw[LPR * LPS] - ra, db = pw[2 * LPR * LPS] - rb;
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(pw[0] - rl <= el) & __builtin_amdgcn_ballot_w64(da * da + db * db <= ec));
+            }
+        packed |= (unsigned)c << (4 * k);
+    }
+    return packed;
+}
+
 }  // namespace
 
 struct AhdParams {
@@ -255,10 +296,14 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     if (p.H < 0) s_pad[threadIdx.x] = 1.0f;
 #endif
     __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 1];                    // 12 KB of closed-form tables (Lab mode 0 only; mode 1 reads its grid from L2)
+    // HDR metric only: did this workgroup write a non-finite L (= luma, ahd.py:55,59) into the Lab buffer of direction H / V?  Only then do the votes need their
+    // literal nine-cell form; every other workgroup takes the fast form, whose shortcuts hold for finite values (round 3: 2 642 -> about 2 400 executed instructions)
+    __shared__ int s_nonfinite[HDR ? 2 : 1];
     const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
 
     const int tid = threadIdx.x;
     AHD_STAMP(0);
+    if (HDR && tid < 2) s_nonfinite[tid] = 0;                                   // (the first barrier below orders it before any P2)
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
     int tbx, tby;
     xcd_tile(tbx, tby);
@@ -368,6 +413,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     for (int dir = 0; dir < 2; dir++) {
         // ---- P2: high-pass of green, photosite-aware resampling of R and B, second white balance + CCM + Lab -> LDS
         float rr[QPT][4], gg[QPT][4], bb[QPT][4];
+        bool nonfinite_l = false;              // HDR: this thread wrote a NaN / Inf luma into the Lab buffer of this direction
         auto candidate = [&](const int q) {
             const Quad& c = qc[q];
             const int gy = c.gy, gx = c.gx, my = c.my, mx = c.mx;
@@ -413,6 +459,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             float* const pl = lab + (2 * c.lqy + 1) * LPS + 2 * c.lqx + 1;
             float L, A, Bq;
             homog_lab<LAB>(lt, p.lablut, rr[q][k], gg[q][k], bb[q][k], p.wb, M, HDR, L, A, Bq);
+            if (HDR) nonfinite_l |= !(fabsf(L) < __builtin_inff());
             float* const o = pl + (k >> 1) * LPS + (k & 1);
             o[0] = L; o[LPR * LPS] = A; o[2 * LPR * LPS] = Bq;
             rgbc[k][0] = rr[q][k]; rgbc[k][1] = gg[q][k]; rgbc[k][2] = bb[q][k];
@@ -441,6 +488,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 #endif
             }
         }
+        if (HDR && nonfinite_l) s_nonfinite[dir] = 1;
         AHD_STAMP(dir == 0 ? 5 : 9);      // P2 done
         __syncthreads();   // Lab of this direction complete; every thread is done with gq
         AHD_STAMP(dir == 0 ? 6 : 10);
@@ -452,31 +500,47 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             if (!c.active) continue;
             const int lqy = c.lqy, lqx = c.lqx;
             const bool at_top = c.at_top, at_bot = c.at_bot, at_left = c.at_left, at_right = c.at_right;
-            // the upper pixel pair votes from window rows 0-2, then row 3 arrives (in row 0's registers) for the lower pair: 36 instead of 48 window registers
-            float wl[4][4], wa[4][4], wq[4][4];
+            const bool literal = HDR && __builtin_amdgcn_readfirstlane(s_nonfinite[HDR ? dir : 0]) != 0;      // uniform over the workgroup
+            // the upper pixel pair votes from window rows 0-2, then row 3 arrives (in row 0's registers) for the lower pair: 36 instead of 48 window registers.
+            // HDR metric: L = luma (ahd.py:55,59) may be NaN or +-Inf, and then the comparisons the fast form takes for granted are false: a workgroup that wrote
+            // such a value votes in the literal nine-cell form (LIT), every other one in the fast form; the two are separate code (one uniform branch around the whole vote)
             int cnt[4];
-            float pc[6];               // chroma distances of the quad's six pixel pairs (vote_quad)
+            auto votes = [&](auto LIT) {
+                constexpr bool LITERAL = decltype(LIT)::value;
+                float wl[4][4], wa[4][4], wq[4][4];
+                float pc[6];               // chroma distances of the quad's six pixel pairs (vote_quad)
 #ifdef AHD_VOTE_WHOLE_WINDOW
-            load_lab_win(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
-            load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
-            load_lab_win(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
-            // HDR metric: L = luma (ahd.py:55,59) may be NaN or +-Inf, and then the comparisons the fast form takes for granted
-            // are false; the literal nine-cell form is used throughout
-            if (HDR) { if (dir == 0) vote_quad_literal<0>(wl, wa, wq, cnt); else vote_quad_literal<1>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 0, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 4>(wl, wa, wq, cnt, pc); }
+                load_lab_win(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
+                load_lab_win(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
+                load_lab_win(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+                if (LITERAL) { if (dir == 0) vote_quad_literal<0>(wl, wa, wq, cnt); else vote_quad_literal<1>(wl, wa, wq, cnt); }
+                else { if (dir == 0) vote_quad<0, 0, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 4>(wl, wa, wq, cnt, pc); }
 #else
-            load_lab_rows<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
-            load_lab_rows<0, 3>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
-            load_lab_rows<0, 3>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
-            if (HDR) { if (dir == 0) vote_quad_literal<0, 0, 2>(wl, wa, wq, cnt); else vote_quad_literal<1, 0, 2>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 2>(wl, wa, wq, cnt, pc); }
-            __builtin_amdgcn_sched_barrier(0);
-            load_lab_rows<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
-            load_lab_rows<3, 4>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
-            load_lab_rows<3, 4>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
-            if (HDR) { if (dir == 0) vote_quad_literal<0, 2, 4>(wl, wa, wq, cnt); else vote_quad_literal<1, 2, 4>(wl, wa, wq, cnt); }
-            else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc); }
+                load_lab_rows<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
+                load_lab_rows<0, 3>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
+                load_lab_rows<0, 3>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+                if (LITERAL) { if (dir == 0) vote_quad_literal<0, 0, 2>(wl, wa, wq, cnt); else vote_quad_literal<1, 0, 2>(wl, wa, wq, cnt); }
+                else { if (dir == 0) vote_quad<0, 0, 2>(wl, wa, wq, cnt, pc); else vote_quad<1, 0, 2>(wl, wa, wq, cnt, pc); }
+                __builtin_amdgcn_sched_barrier(0);
+                load_lab_rows<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl);
+                load_lab_rows<3, 4>(lab + LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wa);
+                load_lab_rows<3, 4>(lab + 2 * LPR * LPS, lqy, lqx, at_top, at_bot, at_left, at_right, wq);
+                if (LITERAL) { if (dir == 0) vote_quad_literal<0, 2, 4>(wl, wa, wq, cnt); else vote_quad_literal<1, 2, 4>(wl, wa, wq, cnt); }
+                else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc); }
 #endif
+            };
+            if constexpr (HDR) {
+                if (literal) {
+                    const unsigned pk = dir == 0 ? vote_quad_literal_lds<0>(lab, lqy, lqx, at_top, at_bot, at_left, at_right)
+                                                 : vote_quad_literal_lds<1>(lab, lqy, lqx, at_top, at_bot, at_left, at_right);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) cnt[k] = (int)((pk >> (4 * k)) & 15u);
+                } else {
+                    votes(std::false_type{});
+                }
+            } else {
+                votes(std::false_type{});
+            }
             if (dir == 0) {
                 hvotes[q] = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
             } else {

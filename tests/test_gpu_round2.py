@@ -164,6 +164,29 @@ def test_non_finite_mosaic_matches_literal_oracle(orc, wbobj):
             assert (~near).sum() > 1500 and np.array_equal(got[~near], ref[~near]), hdr
 
 
+def test_hdr_votes_fast_and_literal_workgroups_in_one_launch(orc, wbobj):
+    """Round 3: with the HDR metric a workgroup votes in the literal nine-cell form only if it wrote a non-finite luma into its Lab buffer (k_ahd.hip,
+    s_nonfinite); every other workgroup takes the fast form.  A frame of 15 x 21 tiles whose few NaN / Inf sites sit in tile interiors, on tile seams
+    and in tile corners (so that a neighbour sees them only in its halo) against the oracle's literal vote everywhere, bit for bit; and the same frame clean."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    pipe = DevicePipeline(0)
+    H, W = 420, 588
+    clean = rggb_frame(H, W, 4242, scale=3.0, clip_hi=False)
+    for sites in ((), ((200, 300, np.nan),), ((27, 27, np.inf), (28, 28, np.nan), (55, 83, -np.inf), (56, 84, np.inf), (139, 0, np.nan), (419, 587, np.inf), (251, 336, np.nan), (252, 335, np.inf))):
+        bay = clean.copy()
+        for y, x, v in sites:
+            bay[y, x] = v
+        d = torch.from_numpy(bay).cuda()
+        ref = orc.demosaic_ahd(bay, wb, M, True, 0)
+        assert np.isnan(ref).any() == bool(sites)
+        assert _same(pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, True, 0).cpu().numpy(), ref), len(sites)
+        assert _same(pipe.demosaic_to_srgb(d, wb, M, _lib.QUALITY_BEST, True, 0, True).cpu().numpy(), orc.pipeline_srgb(bay, wb, M, 2, True, 0, True)), len(sites)
+
+
 def test_non_finite_from_the_products_own_flat_field(orc, wbobj):
     """raw_correction.py:45 on a region where image and flat are both zero leaves NaN in the mosaic; that mosaic then goes
     through the README recipe (drop-in classes), equal to the oracle including the NaN positions."""
