@@ -71,7 +71,7 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
         return None
     K = len(valid)
     target_ev, ev_offsets = _ev_offsets([e.current_ev for e in valid], target_ev)
-    first = in_exposures[0]
+    first = valid[0]
     shape = tuple(first._dev.shape) if (first._dev is not None and first._dev.on_device) else tuple(first.image.shape)     # (no download just to ask)
     if any(e._wb_normalized for e in valid):
         raise NotImplementedError("normalised white balance (wb_norm=True) is not produced by any demosaic path and is not fused on the GPU")
@@ -82,7 +82,7 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
     kmax = max(k for k, off in enumerate(ev_offsets) if off == np.max(ev_offsets))        # :67-68, last match wins
     from .colorize.transform import final_matrix
     from .device_array import DeviceArray, as_device, lazy_enabled
-    M = _lib.mat9(final_matrix(in_exposures[0].mat_xyz))
+    M = _lib.mat9(final_matrix(in_exposures[0].mat_xyz))      # (raw_hdr.py:81 takes the first exposure's matrix, valid or not)
     # Device resident: an exposure that a demosaic left in HBM is fused there (no download + private copy + upload per exposure); host images are
     # uploaded once, straight from the caller's arrays, which stay untouched -- the round trip lands in new buffers, as the reference's
     # wb_undo() / wb_apply() rebind exposure.image to new arrays.
