@@ -74,6 +74,14 @@ int pysp_lab_tables(float *dec, float *cb);
 int pysp_ctx_set_lab_mode(pysp_ctx *ctx, int mode);
 int pysp_ctx_get_lab_mode(pysp_ctx *ctx);
 int pysp_lab_cv410_lut(int16_t *out);
+/* The grid of mode 1 as DATA (round 4).  cv2.cvtColor(COLOR_RGB2LAB) at debayer/ahd.py:58,62 interpolates a 33^3 table that this library can only
+ * restate (no cv2 in the build image); pysp_ctx_set_lab_lut replaces the context's table by `grid` -- 33*33*33*3 int16, [B][G][R] node order, (L, a, b) per
+ * node scaled as OpenCV's RGB2LabLUT_s16 (L*2^14/100, (a+128)*2^14/256, (b+128)*2^14/256; entries in [0, 32767], negative ones are refused) -- or
+ * restores the built-in one (grid == NULL).  tools/gen_cv2_goldens.py records the real table (cv2.cvtColor at the node inputs (p/32, q/32, r/32): every
+ * interpolation weight but one is zero there) so that a 1-LSB disagreement becomes a data change.  Waits for the context's stream, then uploads (2.5 MB).
+ * pysp_ctx_get_lab_lut copies the table in use into out[33*33*33*3]. */
+int pysp_ctx_set_lab_lut(pysp_ctx *ctx, const int16_t *grid);
+int pysp_ctx_get_lab_lut(pysp_ctx *ctx, int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
  * the context's stream; waits for completion).  A host call on a frame of more than 4 MP runs in overlapped

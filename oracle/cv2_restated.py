@@ -202,8 +202,24 @@ def cv410_lab_lut():
     return _CV_LUT["lut"]
 
 
+def set_cv410_lab_lut(grid=None):
+    """Inject a (33,33,33,3) int16 grid for the "cv410_lut" restatement (None: back to the built-in closed-form grid) -- the same switch as
+    oracle.set_cv410_lut and the product's pysp_ctx_set_lab_lut: a table recorded from real cv2 at the grid nodes becomes data."""
+    if grid is None:
+        _CV_LUT.pop("injected", None)
+        return
+    g = np.ascontiguousarray(grid, dtype=np.int16)
+    if g.shape != (33, 33, 33, 3) or (g < 0).any():
+        raise ValueError("Lab grid must be (33, 33, 33, 3) int16 with entries in [0, 32767]")
+    _CV_LUT["injected"] = g.copy()
+
+
+def active_cv410_lab_lut():
+    return _CV_LUT["injected"] if "injected" in _CV_LUT else cv410_lab_lut()
+
+
 def _lab_cv410_lut(src):
-    lut = cv410_lab_lut().astype(np.int32)
+    lut = active_cv410_lab_lut().astype(np.int32)
     with np.errstate(invalid="ignore"):
         v = np.minimum(np.maximum(np.where(np.isnan(src), _F(0), src), _F(0)), _F(1)).astype(np.float32)
     iv = np.rint(v * _F(16384)).astype(np.int32)                      # cvRound: round half to even

@@ -216,6 +216,18 @@ def cv410_lut() -> np.ndarray:
     return out
 
 
+def set_cv410_lut(grid=None) -> None:
+    """Inject a (33,33,33,3) int16 Lab grid for lab mode 1 ([B][G][R] node, (L, a, b) scaled as OpenCV's RGB2LabLUT_s16), or None for the built-in one.
+    Process-wide, like set_lab_mode; tests that inject restore with set_cv410_lut(None)."""
+    if grid is None:
+        _chk(lib().orc_set_cv410_lut(None), "set_cv410_lut")
+        return
+    g = np.ascontiguousarray(grid, dtype=np.int16)
+    if g.shape != (33, 33, 33, 3):
+        raise ValueError("Lab grid must have shape (33, 33, 33, 3)")
+    _chk(lib().orc_set_cv410_lut(_p(g, ctypes.c_int16)), "set_cv410_lut")
+
+
 def lab_tables():
     dec = np.empty((321, 4), np.float32); cb = np.empty((257, 4), np.float32)
     lib().orc_lab_tables(_p(dec), _p(cb)); return dec, cb

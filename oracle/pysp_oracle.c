@@ -247,6 +247,17 @@ int orc_cv410_lut(int16_t *out /* 33*33*33*3 */) {
     memcpy(out, cv410_lut, sizeof(cv410_lut));
     return ORC_OK;
 }
+/* The grid as DATA (round 4): replaces the 33^3 x 3 int16 table of lab mode 1 by the caller's (NULL: back to the built-in one).  The day a machine with
+ * opencv_python==4.10.0.84 is at hand, tools/gen_cv2_goldens.py records cv2.cvtColor at the 35 937 node inputs (p/32, q/32, r/32) -- at a node every
+ * interpolation weight but one is zero, so the output IS the table entry -- and the real table is injected here and in the product
+ * (pysp_ctx_set_lab_lut) without touching code.  Entries must lie in [0, 32767] (OpenCV's own: L*2^14/100 in [0, 16384], (a+128)*64 in [0, 16320]). */
+int orc_set_cv410_lut(const int16_t *grid /* 33*33*33*3 or NULL */) {
+    if (!grid) { cv410_build(); return ORC_OK; }
+    for (size_t i = 0; i < (size_t)33 * 33 * 33 * 3; i++) if (grid[i] < 0) return ORC_EBADARG;
+    memcpy(cv410_lut, grid, sizeof(cv410_lut));
+    cv410_ready = 1;
+    return ORC_OK;
+}
 static inline int cv410_q(float v) {
     v = v > 0.0f ? v : 0.0f;   /* max(v, 0): a NaN comes out as 0 */
     v = v < 1.0f ? v : 1.0f;

@@ -15,6 +15,7 @@ _POOL: Optional[ThreadPoolExecutor] = None
 _POOL_N = 0
 _POOL_PID = 0                           # a forked child inherits the object but not its threads: it builds its own
 _POOL_LOCK = threading.Lock()
+_OLD_POOLS: list = []                  # pools of earlier team sizes stay alive: a concurrent pmap may still be submitting to one
 MIN_PARALLEL_ELEMS = 1 << 18          # below this the serial pass is faster than the hand-off
 
 
@@ -39,8 +40,16 @@ def _cpu_share() -> int:
     return max(1, min(n, 16))
 
 
+_TEAM_CACHE = (None, 0)                 # (value of PYSP_HOST_THREADS the size was computed under, size)
+
+
 def team() -> int:
-    return _cpu_share()
+    """Team size; the affinity mask and the cgroup limit are read once per value of PYSP_HOST_THREADS, not on every call."""
+    global _TEAM_CACHE
+    env = os.environ.get("PYSP_HOST_THREADS")
+    if _TEAM_CACHE[1] == 0 or _TEAM_CACHE[0] != env:
+        _TEAM_CACHE = (env, _cpu_share())
+    return _TEAM_CACHE[1]
 
 
 def _pool(n: int) -> ThreadPoolExecutor:
@@ -49,7 +58,7 @@ def _pool(n: int) -> ThreadPoolExecutor:
     with _POOL_LOCK:
         if _POOL is None or _POOL_N != n or _POOL_PID != pid:
             if _POOL is not None and _POOL_PID == pid:
-                _POOL.shutdown(wait=False)          # tasks already queued still run; callers holding the old pool finish on it
+                _OLD_POOLS.append(_POOL)            # never shut down under a caller (its idle threads cost nothing; team sizes change rarely)
             _POOL, _POOL_N, _POOL_PID = ThreadPoolExecutor(max_workers=n, thread_name_prefix="pysp-host"), n, pid
         return _POOL
 

@@ -82,9 +82,14 @@ def empty(shape, dtype=np.float32) -> np.ndarray:
             del _free[key]
             _idle -= n
             addr = key[1]
-        elif _out + _idle + n > PINNED_CAP:
-            _give_back(drop)
-            return np.empty(shape, dtype)
+        else:
+            while _out + _idle + n > PINNED_CAP and _free:       # idle blocks of OTHER sizes go first: pageable memory is the last resort
+                (m, a), _ = _free.popitem(last=False)
+                _idle -= m
+                drop.append(a)
+            if _out + n > PINNED_CAP:
+                _give_back(drop)
+                return np.empty(shape, dtype)
         _out += n
     _give_back(drop)
     if addr is None:

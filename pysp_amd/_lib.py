@@ -39,6 +39,8 @@ _SIGNATURES = {
     "pysp_ctx_set_lab_mode": (_int, [_vp, _int]),
     "pysp_ctx_get_lab_mode": (_int, [_vp]),
     "pysp_lab_cv410_lut": (_int, [_vp]),
+    "pysp_ctx_set_lab_lut": (_int, [_vp, _vp]),
+    "pysp_ctx_get_lab_lut": (_int, [_vp, _vp]),
     "pysp_ctx_set_stream": (_int, [_vp, _vp]),
     "pysp_ctx_get_stream": (_vp, [_vp]),
     "pysp_lab_tables": (_int, [_f32p, _f32p]),
@@ -187,6 +189,23 @@ class Context:
 
     def get_lab_mode(self) -> int:
         return int(lib().pysp_ctx_get_lab_mode(self.handle))
+
+    def set_lab_lut(self, grid=None) -> None:
+        """The 33^3 grid of lab mode 1 as data: a (33,33,33,3) int16 array ([B][G][R] node, (L, a, b) scaled as OpenCV's RGB2LabLUT_s16) recorded
+        from real cv2 by tools/gen_cv2_goldens.py, or None for the built-in restatement."""
+        if grid is None:
+            check(lib().pysp_ctx_set_lab_lut(self.handle, None))
+            return
+        g = np.ascontiguousarray(grid, dtype=np.int16)
+        if g.shape != (33, 33, 33, 3):
+            raise ValueError("Lab grid must have shape (33, 33, 33, 3)")
+        with self.lock:
+            check(lib().pysp_ctx_set_lab_lut(self.handle, ctypes.c_void_p(g.ctypes.data)))
+
+    def get_lab_lut(self) -> np.ndarray:
+        out = np.empty((33, 33, 33, 3), np.int16)
+        check(lib().pysp_ctx_get_lab_lut(self.handle, ctypes.c_void_p(out.ctypes.data)))
+        return out
 
     def set_stream(self, stream: int) -> None:
         """Bind to a caller-owned hipStream_t (0 = the device's default stream), e.g. torch's current stream."""

@@ -39,6 +39,11 @@ class RawDemosaicData:
             self._dev = None
         return self._img
 
+    def _device_image(self):
+        """The device copy while it is still THE image (None once a host copy has been handed out or the buffer released)."""
+        d = self._dev
+        return d if d is not None and d.on_device else None
+
     @image.setter
     def image(self, value):
         if isinstance(value, DeviceArray) and value.on_device:
@@ -48,20 +53,21 @@ class RawDemosaicData:
 
     def __getstate__(self):
         """State for copy / deepcopy / pickle: the image as a host ndarray (a device buffer is never copied or sent to another process)."""
-        st = self.__dict__.copy()
-        if st.get("_dev") is not None:
-            st["_img"], st["_dev"] = st["_dev"].numpy(), None
-        return st
+        # resolve through the property first: DeviceArray.numpy() releases the device buffer, so the ORIGINAL must switch to the host copy too
+        # (ADVICE r3: a later wb_undo() / fusion on the original found a released _dev and _img None)
+        _ = self.image
+        return self.__dict__.copy()
 
     def is_valid(self) -> bool:
         """Image, coefficients, matrix and exposure value are all present."""
-        have = (self._dev is not None or self._img is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
+        have = (self._device_image() is not None or self._img is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
         return all(have)
 
     def _gpu_scale(self, undo: bool):
-        if self._dev is not None:                      # still in HBM: scale there, stay there
-            dst = DeviceArray(self._dev.context, self._dev.shape)
-            _lib.check(_lib.lib().pysp_wb_scale_dev(self._dev.context.handle, self._dev.ptr, self._dev.size // 3, _lib.wb3(self._wb_coeff), int(undo), dst.ptr))
+        dev = self._device_image()
+        if dev is not None:                            # still in HBM: scale there, stay there
+            dst = DeviceArray(dev.context, dev.shape)
+            _lib.check(_lib.lib().pysp_wb_scale_dev(dev.context.handle, dev.ptr, dev.size // 3, _lib.wb3(self._wb_coeff), int(undo), dst.ptr))
             return dst
         src = _lib.f32c(self.image)
         dst = _lib.empty_f32(src.shape)
@@ -88,7 +94,8 @@ class RawDemosaicData:
     def to_lin_srgb(self) -> np.ndarray:
         """Linear sRGB through the camera matrix, highlights clipped (image_base.py:62-64)."""
         self.wb_apply()
-        return cam_to_lin_srgb(self._dev if self._dev is not None else self.image, self.mat_xyz)
+        dev = self._device_image()
+        return cam_to_lin_srgb(dev if dev is not None else self.image, self.mat_xyz)
 
 
 class RawCameraData_BaseType:

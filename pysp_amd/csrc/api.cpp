@@ -64,6 +64,7 @@ struct pysp_ctx {
     float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
     int lab_mode = 1;            // 1 (default): OpenCV 4.10's LUT + trilinear restatement; 0: closed-form Lab (tables above)
     void* lablut = nullptr;      // mode 1: [34][34][34] x 64 B grid (devmath.h)
+    std::vector<int16_t> lab_grid;   // the 33^3 x 3 grid the device copy was built from (built-in restatement, or injected: pysp_ctx_set_lab_lut)
     Timeline tl;
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
     hipStream_t copy_stream = nullptr;
@@ -169,9 +170,7 @@ void host_cv410_lut(int16_t* out /* 33*33*33*3 */) {
             }
 }
 // device layout of devmath.h::rgb2lab_cv410
-static void host_cv410_device_lut(std::vector<int16_t>& dev) {
-    std::vector<int16_t> lut(33 * 33 * 33 * 3);
-    host_cv410_lut(lut.data());
+static void host_cv410_device_lut(std::vector<int16_t>& dev, const int16_t* lut /* 33*33*33*3, [B][G][R] node, (L, a, b) */) {
     const int D = 34;
     dev.assign((size_t)D * D * D * 32, 0);
     auto at = [&](int z, int y, int x, int c) { z = z > 32 ? 32 : z; y = y > 32 ? 32 : y; x = x > 32 ? 32 : x; return lut[((size_t)(z * 33 + y) * 33 + x) * 3 + c]; };
@@ -237,7 +236,9 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
         hipMemcpy(c->labtab, lt.data(), lt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "Lab table upload failed"); pysp_ctx_destroy(c); return nullptr; }
     {
         std::vector<int16_t> dev;
-        host_cv410_device_lut(dev);
+        c->lab_grid.resize((size_t)33 * 33 * 33 * 3);
+        host_cv410_lut(c->lab_grid.data());
+        host_cv410_device_lut(dev, c->lab_grid.data());
         if (hipMalloc(&c->lablut, dev.size() * sizeof(int16_t)) != hipSuccess ||
             hipMemcpy(c->lablut, dev.data(), dev.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "Lab grid upload failed"); pysp_ctx_destroy(c); return nullptr; }
     }
@@ -276,6 +277,31 @@ int pysp_ctx_set_lab_mode(pysp_ctx* ctx, int mode) {
     return PYSP_OK;
 }
 int pysp_ctx_get_lab_mode(pysp_ctx* ctx) { return ctx ? ctx->lab_mode : -1; }
+
+int pysp_ctx_set_lab_lut(pysp_ctx* ctx, const int16_t* grid) {
+    CTX_ENTER(ctx);
+    std::vector<int16_t> g((size_t)33 * 33 * 33 * 3);
+    if (grid) {
+        for (size_t i = 0; i < g.size(); i++) {
+            if (grid[i] < 0) return fail(PYSP_EBADARG, "pysp_ctx_set_lab_lut: entry %zu is negative (%d); entries are 14/15-bit unsigned values in int16", i, (int)grid[i]);
+            g[i] = grid[i];
+        }
+    } else {
+        host_cv410_lut(g.data());
+    }
+    std::vector<int16_t> dev;
+    host_cv410_device_lut(dev, g.data());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));          // kernels already enqueued still read the old grid
+    HIP_TRY(hipMemcpy(ctx->lablut, dev.data(), dev.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    ctx->lab_grid.swap(g);
+    return PYSP_OK;
+}
+int pysp_ctx_get_lab_lut(pysp_ctx* ctx, int16_t* out) {
+    CTX_ENTER(ctx);
+    if (!out) return fail(PYSP_EBADARG, "pysp_ctx_get_lab_lut: null output");
+    memcpy(out, ctx->lab_grid.data(), ctx->lab_grid.size() * sizeof(int16_t));
+    return PYSP_OK;
+}
 
 int pysp_ctx_set_stream(pysp_ctx* ctx, void* stream) {
     CTX_ENTER(ctx);

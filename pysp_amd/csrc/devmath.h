@@ -143,7 +143,8 @@ DEVI int dot2_i16(unsigned v, int w, int acc) {
 // v_mul_u32_u24 spelled out: the compiler turns __umul24 back into a plain multiply and then cannot prove (16 - f) | (f << 16) is a
 // 24-bit value, so it picks v_mul_lo_u32, which issues at a quarter of the rate
 DEVI unsigned mul24(unsigned a, unsigned b) { unsigned d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B, float& L, float& a, float& b) {
+// The three interpolated table values of one pixel, before the float scaling: l in [0, 2^14], a', b' in [0, 2^15) (entries are non-negative: pysp_ctx_set_lab_lut)
+DEVI void rgb2lab_cv410_q(const uint4* __restrict__ lut, float R, float G, float B, int& aL, int& aa, int& ab) {
     // cvRound(clip(v) * 2^14) without a conversion: clip(v) * 2^14 + 1.5 * 2^23 is one exact-product FMA whose rounding IS round-half-even
     // to an integer, and the integer (<= 2^14) then sits in the low mantissa bits: cell = bits 9..14, position = bits 5..8.
     const unsigned bx = __float_as_uint(__builtin_fmaf(clip01_cv(R), 16384.0f, 12582912.0f));
@@ -160,13 +161,26 @@ DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B
     const int w00 = (int)mul24(wxz0, 16u - fy), w10 = (int)mul24(wxz0, fy);   // (dy, dz)
     const int w01 = (int)mul24(wxz1, 16u - fy), w11 = (int)mul24(wxz1, fy);
     // CV_DESCALE's rounding constant 2^11 is the accumulators' start value (integer sums: any order, same bits)
-    int aL = dot2_i16(q2.y, w11, dot2_i16(q1.z, w01, dot2_i16(q0.w, w10, dot2_i16(q0.x, w00, 1 << 11))));
-    int aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 1 << 11))));
-    int ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 1 << 11))));
+    aL = dot2_i16(q2.y, w11, dot2_i16(q1.z, w01, dot2_i16(q0.w, w10, dot2_i16(q0.x, w00, 1 << 11))));
+    aa = dot2_i16(q2.z, w11, dot2_i16(q1.w, w01, dot2_i16(q1.x, w10, dot2_i16(q0.y, w00, 1 << 11))));
+    ab = dot2_i16(q2.w, w11, dot2_i16(q2.x, w01, dot2_i16(q1.y, w10, dot2_i16(q0.z, w00, 1 << 11))));
     aL >>= 12; aa >>= 12; ab >>= 12;
+}
+DEVI void rgb2lab_cv410(const uint4* __restrict__ lut, float R, float G, float B, float& L, float& a, float& b) {
+    int aL, aa, ab;
+    rgb2lab_cv410_q(lut, R, G, B, aL, aa, ab);
     L = (float)aL * (100.0f / 16384.0f);
     a = (float)aa * (256.0f / 16384.0f) - 128.0f;
     b = (float)ab * (256.0f / 16384.0f) - 128.0f;
+}
+// The same pixel with its chroma left as the two table integers, a' | b' << 16 (round 4): a = a'/64 - 128 and b = b'/64 - 128 are exact in float32, so
+// are their differences, and the homogeneity vote (pyx:50-57) only ever uses differences of chroma values: k_ahd_select votes on the integers
+// (v_pk_sub_i16 + v_dot2_i32_i16 per distance instead of two subtractions, two squares and a sum) -- see vote_quad_i16 for when that is exact.
+DEVI void rgb2lab_cv410_pk(const uint4* __restrict__ lut, float R, float G, float B, float& L, unsigned& ab_pk) {
+    int aL, aa, ab;
+    rgb2lab_cv410_q(lut, R, G, B, aL, aa, ab);
+    L = (float)aL * (100.0f / 16384.0f);
+    ab_pk = (unsigned)aa | ((unsigned)ab << 16);
 }
 
 // ---- sRGB transfer curves, transform.py:89-111 -------------------------------------------------

@@ -46,6 +46,10 @@ constexpr int NT_A = LQX * LQY / QPT;              // 256: one thread per quad (
 #define AHD_MIN_WAVES 1                           // the allocator reaches 92 VGPRs unforced; forcing a bound on earlier versions only spilled
 #endif
 
+#ifndef AHD_I16
+#define AHD_I16 1                                 // Lab mode 1: chroma kept as the table's int16 pair in LDS, votes on integers (round 4); 0 = round 3's float planes
+#endif
+
 constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // ahd.py:89-94
 
 // Diagnostic build only (-DAHD_STAMPS, tools/phase_stamps.py): wave 0..3 of every workgroup writes the shader clock (s_memtime) at the phase
@@ -74,6 +78,19 @@ DEVI void homog_lab(LabTab lt, const uint4* lut, float r, float g, float b, cons
         sr = sr / (1.0f + sr); sg = sg / (1.0f + sg); sb = sb / (1.0f + sb);
     }
     if (LAB == 1) rgb2lab_cv410(lut, sr, sg, sb, L, A, Bq); else rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
+    if (hdr) L = luma;
+}
+
+// The same for the packed layout of Lab mode 1 (round 4): L as float, chroma as the two interpolated table integers a' | b' << 16
+DEVI void homog_lab_pk(const uint4* lut, float r, float g, float b, const float wb[3], const double* M, int hdr, float& L, unsigned& ab) {
+    float rr = r * wb[0], gg = g * wb[1], bb = b * wb[2];
+    float sr = ccm_row(M, rr, gg, bb), sg = ccm_row(M + 3, rr, gg, bb), sb = ccm_row(M + 6, rr, gg, bb);
+    float luma = 0.0f;
+    if (hdr) {
+        luma = 0.2126f * sr + 0.7152f * sg + 0.0722f * sb;
+        sr = sr / (1.0f + sr); sg = sg / (1.0f + sg); sb = sb / (1.0f + sb);
+    }
+    rgb2lab_cv410_pk(lut, sr, sg, sb, L, ab);
     if (hdr) L = luma;
 }
 
@@ -255,6 +272,194 @@ DEVI unsigned vote_quad_literal_lds(const float* lab, int lqy, int lqx, bool at_
     return packed;
 }
 
+// ---- Lab mode 1, packed layout (round 4) ------------------------------------------------------------------------------------------------
+// The Lab buffer holds one 8-byte cell { L (float), a' | b' << 16 } per pixel: [LPR][LPS] cells, 9.2 KB instead of the 13.9 KB of three float planes
+// (20.8 KB in all: SEVEN workgroups per CU).  a' and b' are the interpolated table values themselves (15-bit unsigned); the float values cv2 would
+// return are a = a'/64 - 128, b = b'/64 - 128, exact in float32, and the vote (pyx:50-57) uses only their differences:
+//     da = (a'_w - a'_c) / 64 exactly,   fl(da * da) = fl(D^2) / 4096 with D the integer difference (a power-of-two scale commutes with rounding),
+// so the float32 chroma distance is fl(fl(Da^2) + fl(Db^2)) / 4096 and its comparisons are those of fl(fl(Da^2) + fl(Db^2)).
+// While S = Da^2 + Db^2 < 2^24 nothing rounds: the float distance IS the integer S.  The vote compares S_cell <= ec with ec = max(S_n1, S_n2):
+//   * ec < 2^24 and S_cell <= ec: all three exact, same answer;
+//   * ec < 2^24 and S_cell > ec: if S_cell < 2^24 it is exact, same answer; if S_cell >= 2^24 then either one square is >= 2^24 already, or both are
+//     exact and their exact sum is >= 2^24 -- float rounding is monotone and 2^24 is a float, so the float distance is >= 2^24 > ec: same answer.
+// So the integer vote is bit-identical to the float one whenever every ec of the wave is below 2^24, i.e. no pixel's chroma differs from one of its two
+// direction neighbours' by 64 Lab units or more -- three v_or and one ballot per direction decide it, and a wave that fails the test (hard colour
+// noise; never on the benchmark scene) computes its distances as float32 sums of float32 squares of the integer differences (chroma_d2_f32).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+DEVI unsigned chroma_d2(unsigned x, unsigned y) {                 // (a'x - a'y)^2 + (b'x - b'y)^2: v_pk_sub_i16 + v_dot2_i32_i16
+    const s16x2 d = __builtin_bit_cast(s16x2, x) - __builtin_bit_cast(s16x2, y);      // |difference| <= 32767: no wrap
+    return (unsigned)__builtin_amdgcn_sdot2(d, d, 0, false);                          // <= 2 * 32767^2 < 2^31
+}
+constexpr int LC4 = LPS / 2;                                      // float4 (two cells) per Lab row
+static_assert(LPS % 2 == 0, "Lab rows are whole float4s");
+// Rows [R0, R1) of the 4x4 window of cells around a quad (rows / cols -1..2 of the quad's top-left pixel), 16-byte reads; BORDER_REFLECT (ahd.py:64) duplicates
+// the edge pixel.  As in round 3 the window comes in two pieces -- rows 0-2 for the quad's upper pixel pair, then row 3 in row 0's registers for the lower
+// pair -- 24 window registers instead of 32 (the kernel has to stay at 72 VGPRs for seven waves per SIMD).
+template <int R0, int R1>
+DEVI void load_labrows_pk(const float* lab, int lqy, int lqx, bool at_top, bool at_bot, bool at_left, bool at_right, float wl[4][4], unsigned wc[4][4]) {
+    const float4* p = reinterpret_cast<const float4*>(lab) + (2 * lqy) * LC4 + lqx;
+#pragma unroll
+    for (int r = R0; r < R1; r++) {
+        const float4 a = p[r * LC4], b = p[r * LC4 + 1];
+        wl[r][0] = a.x; wc[r][0] = __float_as_uint(a.y); wl[r][1] = a.z; wc[r][1] = __float_as_uint(a.w);
+        wl[r][2] = b.x; wc[r][2] = __float_as_uint(b.y); wl[r][3] = b.z; wc[r][3] = __float_as_uint(b.w);
+    }
+    if (at_top | at_bot | at_left | at_right) {   // interior waves skip the selects
+#pragma unroll
+        for (int r = R0; r < R1; r++) {
+            if (at_left) { wl[r][0] = wl[r][1]; wc[r][0] = wc[r][1]; }
+            if (at_right) { wl[r][3] = wl[r][2]; wc[r][3] = wc[r][2]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (R0 == 0 && at_top) { wl[0][c] = wl[1][c]; wc[0][c] = wc[1][c]; }
+            if (R1 == 4 && at_bot) { wl[3][c] = wl[2][c]; wc[3][c] = wc[2][c]; }      // row 2 already carries its left / right rule
+        }
+    }
+}
+// The same distance the way the float32 reference rounds it, for the waves the integer form cannot serve: the integer differences as floats (exact),
+// their squares and the sum rounded like cv2's a, b would give them (scaled by 4096, a power of two).  Eight instructions instead of two.
+DEVI float chroma_d2_f32(unsigned x, unsigned y) {
+    asm volatile("" : "+v"(x));          // (not the integer form's subtraction: see vote_quad_pk_f32 on hoisting)
+    const s16x2 d = __builtin_bit_cast(s16x2, x) - __builtin_bit_cast(s16x2, y);
+    const float da = (float)(int)d.x, db = (float)(int)d.y;
+    return da * da + db * db;
+}
+// Which of the quad's six pixel pairs (quad_pair_id) already sit in pc[] when the integer vote of pixels [K0, K1) reaches its cells: a compile-time fact of the
+// processing order (epsilon step of the piece first, then its pixels in order).  Piece 1 (K0 = 0) starts empty and its epsilon step adds the direction's upper
+// pair(s); piece 2 (K0 = 2) inherits everything piece 1 produced (all pairs but (2,3), id 1) and its epsilon step adds (2,3) when the direction is horizontal.
+template <int DIR, int K0>
+DEVI void pairs_ready(bool have[6]) {
+    const bool second = K0 == 2;
+    have[0] = second || DIR == 0; have[1] = second && DIR == 0; have[2] = second || DIR == 1; have[3] = second || DIR == 1; have[4] = second; have[5] = second;
+}
+// pyx:22-58 for pixels [K0, K1) of a quad on the packed window, integer chroma.  Step 1 (eps): the chroma distances to the two direction neighbours of every
+// pixel and their maximum ec[k]; distances between two pixels of the quad go through the pair table pc[] (vote_quad).
+template <int DIR, int K0, int K1>
+DEVI void vote_eps_pk(const unsigned wc[4][4], unsigned ec[4], unsigned pc[6]) {
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int ny[2] = {DIR ? cy - 1 : cy, DIR ? cy + 1 : cy}, nx[2] = {DIR ? cx : cx - 1, DIR ? cx : cx + 1};
+        unsigned c[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int y = ny[j], x = nx[j];
+            const bool quad = y >= 1 && y <= 2 && x >= 1 && x <= 2;
+            const int q = quad ? (y - 1) * 2 + (x - 1) : -1;
+            if (quad && q < k) { c[j] = pc[quad_pair_id(k, q)]; continue; }
+            c[j] = chroma_d2(wc[y][x], wc[cy][cx]);
+            if (quad) pc[quad_pair_id(k, q)] = c[j];
+        }
+        ec[k] = c[0] > c[1] ? c[0] : c[1];
+    }
+}
+// Step 2: the counts.  The centre and the two epsilon neighbours always count (as in vote_quad); the other six cells are tested: float L difference against
+// the float epsilon, integer chroma distance against ec[k]; the quad's other pixel pairs come from / go into pc[].
+template <int DIR, int K0, int K1>
+DEVI void vote_cells_pk(const float wl[4][4], const unsigned wc[4][4], const unsigned ec[4], unsigned pc[6], int cnt[4]) {
+    bool have[6];
+    pairs_ready<DIR, K0>(have);
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
+        const float rl = wl[cy][cx];
+        const float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
+        float el;
+        asm("v_max_f32 %0, %1, %2" : "=v"(el) : "v"(e1), "v"(e2));
+        int c = 3;
+#pragma unroll
+        for (int wy = 0; wy < 3; wy++)
+#pragma unroll
+            for (int wx = 0; wx < 3; wx++) {
+                const int y = dy + wy, x = dx + wx;
+                if ((y == cy && x == cx) || (y == n1y && x == n1x) || (y == n2y && x == n2x)) continue;
+                const bool quad = y >= 1 && y <= 2 && x >= 1 && x <= 2;
+                const int q = quad ? (y - 1) * 2 + (x - 1) : -1;
+                unsigned d;
+                if (quad && have[quad_pair_id(k, q)]) d = pc[quad_pair_id(k, q)];
+                else {
+                    d = chroma_d2(wc[y][x], wc[cy][cx]);
+                    if (quad) { pc[quad_pair_id(k, q)] = d; have[quad_pair_id(k, q)] = true; }
+                }
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(wl[y][x] - rl <= el) & __builtin_amdgcn_ballot_w64(d <= ec[k]));
+            }
+        cnt[k] = c;
+    }
+}
+// The rare exact-float form (a wave whose guard failed): pixel by pixel, every distance recomputed as chroma_d2_f32, nothing shared, one cell at a time --
+// built for a small register footprint (it must not raise the kernel's VGPR count above the integer form's), not for speed.  Returns the counts of
+// pixels [K0, K1), 4 bits each.
+template <int DIR, int K0, int K1>
+DEVI unsigned vote_quad_pk_f32(const float wl[4][4], const unsigned wc[4][4]) {
+    unsigned packed = 0;
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
+        float rl = wl[cy][cx];
+        // (this form's arithmetic must not look like the integer form's: the compiler would hoist the common L differences and packed subtractions above the
+        // wave-uniform branch between the two forms and keep them in registers across it -- 102 VGPRs instead of 72; hence the opaque copies)
+        asm volatile("" : "+v"(rl));
+        const float e1 = fabsf(rl - wl[n1y][n1x]), e2 = fabsf(rl - wl[n2y][n2x]);
+        const float c1 = chroma_d2_f32(wc[n1y][n1x], wc[cy][cx]), c2 = chroma_d2_f32(wc[n2y][n2x], wc[cy][cx]);
+        float el, ec;
+        asm("v_max_f32 %0, %1, %2" : "=v"(el) : "v"(e1), "v"(e2));
+        asm("v_max_f32 %0, %1, %2" : "=v"(ec) : "v"(c1), "v"(c2));
+        int c = 3;
+#pragma unroll
+        for (int wy = 0; wy < 3; wy++)
+#pragma unroll
+            for (int wx = 0; wx < 3; wx++) {
+                const int y = dy + wy, x = dx + wx;
+                if ((y == cy && x == cx) || (y == n1y && x == n1x) || (y == n2y && x == n2x)) continue;
+                __builtin_amdgcn_sched_barrier(0);
+                const float d = chroma_d2_f32(wc[y][x], wc[cy][cx]);
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(wl[y][x] - rl <= el) & __builtin_amdgcn_ballot_w64(d <= ec));
+            }
+        packed |= (unsigned)c << (4 * k);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return packed;
+}
+// The literal nine-cell vote from the packed buffer (HDR instance, workgroups that hold a non-finite luma): vote_quad_literal_lds with the chroma read as
+// integers and converted (exact, scale-free: see above)
+template <int DIR>
+DEVI unsigned vote_quad_literal_lds_pk(const float* lab, int lqy, int lqx, bool at_top, bool at_bot, bool at_left, bool at_right) {
+    const float2* const pL = reinterpret_cast<const float2*>(lab) + (2 * lqy) * LPS + 2 * lqx;
+    auto cell = [&](int Y, int X) -> const float2* {
+        Y = (at_top && Y == 0) ? 1 : ((at_bot && Y == 3) ? 2 : Y);
+        X = (at_left && X == 0) ? 1 : ((at_right && X == 3) ? 2 : X);
+        return pL + Y * LPS + X;
+    };
+    auto fa = [](float2 v) { return (float)(__float_as_uint(v.y) & 0xFFFFu); };
+    auto fb = [](float2 v) { return (float)(__float_as_uint(v.y) >> 16); };
+    unsigned packed = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const int dy = k >> 1, dx = k & 1, cy = dy + 1, cx = dx + 1;
+        const int n1y = DIR ? cy - 1 : cy, n1x = DIR ? cx : cx - 1, n2y = DIR ? cy + 1 : cy, n2x = DIR ? cx : cx + 1;
+        const float2 vc = *cell(cy, cx), v1 = *cell(n1y, n1x), v2 = *cell(n2y, n2x);
+        const float rl = vc.x, ra = fa(vc), rb = fb(vc);
+        const float e1 = fabsf(rl - v1.x), e2 = fabsf(rl - v2.x);
+        const float da1 = ra - fa(v1), db1 = rb - fb(v1), da2 = ra - fa(v2), db2 = rb - fb(v2);
+        const float c1 = da1 * da1 + db1 * db1, c2 = da2 * da2 + db2 * db2;
+        const float el = e2 > e1 ? e2 : e1, ec = c2 > c1 ? c2 : c1;
+        int c = 0;
+#pragma unroll 1
+        for (int wy = 0; wy < 3; wy++)
+#pragma unroll 1
+            for (int wx = 0; wx < 3; wx++) {
+                const float2 vw = *cell(dy + wy, dx + wx);
+                const float da = fa(vw) - ra, db = fb(vw) - rb;
+                c = add_lane_bit(c, __builtin_amdgcn_ballot_w64(vw.x - rl <= el) & __builtin_amdgcn_ballot_w64(da * da + db * db <= ec));
+            }
+        packed |= (unsigned)c << (4 * k);
+    }
+    return packed;
+}
+
 }  // namespace
 
 struct AhdParams {
@@ -283,7 +488,8 @@ struct AhdParams {
 // (tools/ab_bench.sh, LDS padding): five -> four workgroups per CU costs this kernel 9 %, four -> three 24 %: it is latency-bound, occupancy is the lever.
 template <bool TINY, bool U16, bool HDR, int LAB, bool TAIL>
 __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
-    constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GX, NLAB = 3 * LPR * LPS;
+    constexpr bool I16 = LAB == 1 && AHD_I16 != 0;      // packed Lab cells { L, a' | b' << 16 } and integer chroma votes (round 4)
+    constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GX, NLAB = (I16 ? 2 : 3) * LPR * LPS;
     static_assert(NMW % 4 == 0 && NGQ % 4 == 0, "16-byte aligned sections");
     __shared__ __attribute__((aligned(16))) float planes[NMW + NGQ + NLAB + 2];     // + 2: the last window row of the last Lab plane is read (never used) one row past LPR
     float* const mw = planes;
@@ -456,12 +662,20 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
         auto lab_px = [&](const int q, const int k) {
             const Quad& c = qc[q];
             float (&rgbc)[4][3] = dir == 0 ? rgbh[q] : rgbv[q];
-            float* const pl = lab + (2 * c.lqy + 1) * LPS + 2 * c.lqx + 1;
-            float L, A, Bq;
-            homog_lab<LAB>(lt, p.lablut, rr[q][k], gg[q][k], bb[q][k], p.wb, M, HDR, L, A, Bq);
-            if (HDR) nonfinite_l |= !(fabsf(L) < __builtin_inff());
-            float* const o = pl + (k >> 1) * LPS + (k & 1);
-            o[0] = L; o[LPR * LPS] = A; o[2 * LPR * LPS] = Bq;
+            if constexpr (I16) {
+                float L; unsigned ab;
+                homog_lab_pk(p.lablut, rr[q][k], gg[q][k], bb[q][k], p.wb, M, HDR, L, ab);
+                if (HDR) nonfinite_l |= !(fabsf(L) < __builtin_inff());
+                float2* const o = reinterpret_cast<float2*>(lab) + (2 * c.lqy + 1 + (k >> 1)) * LPS + 2 * c.lqx + 1 + (k & 1);
+                *o = make_float2(L, __uint_as_float(ab));          // one 8-byte cell per pixel
+            } else {
+                float* const pl = lab + (2 * c.lqy + 1) * LPS + 2 * c.lqx + 1;
+                float L, A, Bq;
+                homog_lab<LAB>(lt, p.lablut, rr[q][k], gg[q][k], bb[q][k], p.wb, M, HDR, L, A, Bq);
+                if (HDR) nonfinite_l |= !(fabsf(L) < __builtin_inff());
+                float* const o = pl + (k >> 1) * LPS + (k & 1);
+                o[0] = L; o[LPR * LPS] = A; o[2 * LPR * LPS] = Bq;
+            }
             rgbc[k][0] = rr[q][k]; rgbc[k][1] = gg[q][k]; rgbc[k][2] = bb[q][k];
         };
         if constexpr (QPT == 1) {
@@ -529,17 +743,41 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
                 else { if (dir == 0) vote_quad<0, 2, 4>(wl, wa, wq, cnt, pc); else vote_quad<1, 2, 4>(wl, wa, wq, cnt, pc); }
 #endif
             };
+            // Lab mode 1, packed cells: integer chroma vote on the whole window; a wave in which some pixel's chroma lies 64 Lab units or more from a direction
+            // neighbour's (ec >= 2^24: float32 rounding of the squares could then matter) recomputes its distances in float32 arithmetic on the same window
+            auto votes_pk = [&]() {
+                float wl[4][4]; unsigned wc[4][4], ec[4], pc[6];
+                bool exact;                                                     // uniform over the wave
+                auto piece = [&](auto DIRC, auto K0C) {
+                    constexpr int D = decltype(DIRC)::value, K0 = decltype(K0C)::value;
+                    vote_eps_pk<D, K0, K0 + 2>(wc, ec, pc);
+                    exact = __builtin_amdgcn_ballot_w64((ec[K0] | ec[K0 + 1]) >= (1u << 24)) == 0 && (K0 == 0 || exact);   // (piece 2's pair table comes from piece 1's integer form)
+                    if (exact) vote_cells_pk<D, K0, K0 + 2>(wl, wc, ec, pc, cnt);
+                    else {
+                        const unsigned pk = vote_quad_pk_f32<D, K0, K0 + 2>(wl, wc);
+                        cnt[K0] = (int)((pk >> (4 * K0)) & 15u); cnt[K0 + 1] = (int)((pk >> (4 * K0 + 4)) & 15u);
+                    }
+                };
+                load_labrows_pk<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
+                if (dir == 0) piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); else piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                load_labrows_pk<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
+                if (dir == 0) piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}); else piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            };
             if constexpr (HDR) {
                 if (literal) {
-                    const unsigned pk = dir == 0 ? vote_quad_literal_lds<0>(lab, lqy, lqx, at_top, at_bot, at_left, at_right)
-                                                 : vote_quad_literal_lds<1>(lab, lqy, lqx, at_top, at_bot, at_left, at_right);
+                    unsigned pk;
+                    if constexpr (I16) pk = dir == 0 ? vote_quad_literal_lds_pk<0>(lab, lqy, lqx, at_top, at_bot, at_left, at_right)
+                                                     : vote_quad_literal_lds_pk<1>(lab, lqy, lqx, at_top, at_bot, at_left, at_right);
+                    else pk = dir == 0 ? vote_quad_literal_lds<0>(lab, lqy, lqx, at_top, at_bot, at_left, at_right)
+                                       : vote_quad_literal_lds<1>(lab, lqy, lqx, at_top, at_bot, at_left, at_right);
 #pragma unroll
                     for (int k = 0; k < 4; k++) cnt[k] = (int)((pk >> (4 * k)) & 15u);
                 } else {
-                    votes(std::false_type{});
+                    if constexpr (I16) votes_pk(); else votes(std::false_type{});
                 }
             } else {
-                votes(std::false_type{});
+                if constexpr (I16) votes_pk(); else votes(std::false_type{});
             }
             if (dir == 0) {
                 hvotes[q] = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);

@@ -11,8 +11,10 @@ call sees, exactly as with the reference's ndarray (a later GPU call uploads the
 code that needs `isinstance(x, np.ndarray)` calls `np.asarray(x)` first, or switches laziness off with `pysp_amd.set_lazy(False)`
 (environment: PYSP_EAGER=1), after which every call returns plain ndarrays exactly like the reference.
 `copy.copy`, `copy.deepcopy` and `pickle` give a plain ndarray with the same values (a device pointer means nothing in a copy or
-in another process).  Buffer calls on the owning context are serialised by the context's lock, so an array may be read, or garbage
-collected, on another thread than the one that made it.
+in another process).  What is thread-safe: the BUFFER calls on the owning context (allocate, free, upload, download, and the whole
+download-and-release step of `numpy()`) are serialised by the context's re-entrant lock, so an array may be materialised, or garbage collected,
+on another thread than the one that made it, also by two threads at once.  What is not: compute calls (demosaic, colour, fusion ...) on one
+context from several threads at a time -- the C context owns one stream and one workspace; use one Context per thread for that.
 """
 from __future__ import annotations
 
@@ -109,12 +111,13 @@ class DeviceArray:
         """The host copy: downloaded on first use, and from then on THE array -- the device copy is released, because the caller now
         holds a writable ndarray whose edits the GPU copy would not see (the reference hands out plain ndarrays)."""
         if self._host is None:
-            out = _lib.empty_f32(self.shape)
-            with self._ctx.lock:
-                _lib.check(_lib.lib().pysp_dev_download(self._ctx.handle, _lib.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
-            self._host = out
-            self._keepalive = None
-            self.release()
+            out = _lib.empty_f32(self.shape)            # outside the lock: the page-locked pool has its own
+            with self._ctx.lock:                        # (re-entrant) check, download and release are ONE step: two threads reading the same
+                if self._host is None:                  # array get the same ndarray, and nobody downloads from a block already back in the cache
+                    _lib.check(_lib.lib().pysp_dev_download(self._ctx.handle, _lib.ptr(out), self.ptr, ctypes.c_size_t(out.nbytes)))
+                    self._host = out
+                    self._keepalive = None
+                    self.release()
         return self._host
 
     # a copy / pickle is a plain ndarray: a device pointer must never exist twice, nor travel to another process

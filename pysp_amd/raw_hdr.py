@@ -72,7 +72,6 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
     K = len(valid)
     target_ev, ev_offsets = _ev_offsets([e.current_ev for e in valid], target_ev)
     first = valid[0]
-    shape = tuple(first._dev.shape) if (first._dev is not None and first._dev.on_device) else tuple(first.image.shape)     # (no download just to ask)
     if any(e._wb_normalized for e in valid):
         raise NotImplementedError("normalised white balance (wb_norm=True) is not produced by any demosaic path and is not fused on the GPU")
     coeff = np.ascontiguousarray(np.stack([np.asarray(e._wb_coeff, dtype=np.float32)[:3] for e in valid]))
@@ -86,28 +85,64 @@ def fuse_exposures_from_debayer(in_exposures: List[RawDemosaicData], target_ev: 
     # Device resident: an exposure that a demosaic left in HBM is fused there (no download + private copy + upload per exposure); host images are
     # uploaded once, straight from the caller's arrays, which stay untouched -- the round trip lands in new buffers, as the reference's
     # wb_undo() / wb_apply() rebind exposure.image to new arrays.
-    ctx = next((e._dev.context for e in valid if e._dev is not None and e._dev.on_device), None) or _lib.default_context()
-    d_in = []
-    for e in valid:
-        src = e._dev if (e._dev is not None and e._dev.on_device) else e._img
-        if tuple(src.shape) != tuple(shape):
-            raise ValueError("all exposures must share one shape")
-        d_in.append(as_device(src, ctx))
-    d_rt = [DeviceArray(ctx, shape) for _ in valid]
-    d_out, d_cnt = DeviceArray(ctx, shape), DeviceArray(ctx, shape)          # the counts are int32 in a buffer of the same size
+    # Exposures of ANOTHER context / device than the first device-resident one are brought over through the host (as_device downloads them, which
+    # releases their device copy, and uploads to `ctx`): correct, one extra PCIe round trip for those exposures only.
+    dev_imgs = [e._device_image() for e in valid]
+    shape = tuple(dev_imgs[0].shape) if dev_imgs[0] is not None else tuple(first.image.shape)     # (no download just to ask)
+    ctx = next((d.context for d in dev_imgs if d is not None), None) or _lib.default_context()
     vpp = ctypes.c_void_p * K
     fp = ctypes.POINTER(ctypes.c_float)
     npx = int(np.prod(shape, dtype=np.int64)) // 3
+    lazy = lazy_enabled()
+    for e, d in zip(valid, dev_imgs):
+        if tuple((d if d is not None else e.image).shape) != tuple(shape):
+            raise ValueError("all exposures must share one shape")
+    try:
+        d_in, d_rt = [], []
+        for e, d in zip(valid, dev_imgs):
+            if d is not None and d.context is ctx:
+                d_in.append(d)
+                d_rt.append(DeviceArray(ctx, shape))       # the exposure's own buffer may be shared with other holders: round trip into a new one
+            else:
+                up = as_device(d if d is not None else e.image, ctx)
+                d_in.append(up)
+                d_rt.append(up)                            # a private upload takes its round trip in place (the header allows d_frames_rt[k] == d_frames[k])
+        d_out, d_cnt = DeviceArray(ctx, shape), DeviceArray(ctx, shape)          # the counts are int32 in a buffer of the same size
+    except MemoryError:
+        # 2K + 2 frames do not fit beside what the context already holds: the host entry point streams the exposures instead
+        d_in = d_rt = None
+        return _fuse_from_debayer_host(valid, shape, coeff, applied, off32, bias, kmax, M, lazy)
     with ctx.lock:
         _lib.check(_lib.lib().pysp_fuse_rgb_dev(ctx.handle, vpp(*[d.ptr.value for d in d_in]), vpp(*[d.ptr.value for d in d_rt]), K, ctypes.c_size_t(npx),
                                                 coeff.ctypes.data_as(fp), applied, off32.ctypes.data_as(fp), bias.ctypes.data_as(fp), kmax, M, d_out.ptr, d_cnt.ptr))
-        count = _lib.empty(shape, np.int32)
+    count = _lib.empty(shape, np.int32)               # allocated outside the context's lock (it may come from the page-locked pool)
+    with ctx.lock:
         _lib.check(_lib.lib().pysp_dev_download(ctx.handle, _lib.ptr(count), d_cnt.ptr, ctypes.c_size_t(count.nbytes)))      # waits for the kernel: the uploads' sources may go
     del d_in, d_cnt
-    lazy = lazy_enabled()
     for e, rt in zip(valid, d_rt):           # the state wb_undo(); wb_apply() leaves behind
         e.image = rt if lazy else rt.numpy()
         e._wb_applied = True
         e._wb_normalized = False
     fused = d_out if lazy else d_out.numpy()
     return (fused, count)
+
+
+def _fuse_from_debayer_host(valid, shape, coeff, applied, off32, bias, kmax, M, lazy):
+    """fuse_exposures_from_debayer through the host-buffer entry point (pysp_fuse_rgb_f32): the fallback when the device-resident form cannot
+    allocate its 2K + 2 frames.  Same kernel, same bits; every exposure ends as a host ndarray holding its wb_undo / wb_apply round trip."""
+    K = len(valid)
+    frames = [np.array(e.image, dtype=np.float32, order="C", copy=True) for e in valid]      # private copies: the caller's arrays stay untouched
+    out = _lib.empty_f32(shape)
+    count = _lib.empty(shape, np.int32)
+    vpp = ctypes.c_void_p * K
+    fp = ctypes.POINTER(ctypes.c_float)
+    npx = int(np.prod(shape, dtype=np.int64)) // 3
+    ctx = _lib.default_context()
+    with ctx.lock:
+        _lib.check(_lib.lib().pysp_fuse_rgb_f32(ctx.handle, vpp(*[f.ctypes.data for f in frames]), K, ctypes.c_size_t(npx), coeff.ctypes.data_as(fp), applied,
+                                                off32.ctypes.data_as(fp), bias.ctypes.data_as(fp), kmax, M, _lib.ptr(out), _lib.ptr(count), 1))
+    for e, f in zip(valid, frames):
+        e.image = f
+        e._wb_applied = True
+        e._wb_normalized = False
+    return (out, count)

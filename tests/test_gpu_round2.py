@@ -439,6 +439,37 @@ def test_lazy_array_edits_copies_and_threads(orc, wbobj):
     dem = RawRggbBayerData(bay, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Fast)
     dem2 = copy.deepcopy(dem)                                  # the container of the reference is deep-copyable: so is this one
     assert np.array_equal(dem2.image, dem.image) and dem2.image is not dem.image
+    # (3b) ADVICE r3: the ORIGINAL keeps working after a copy / pickle WITHOUT anyone reading .image first -- the copy released its device buffer
+    #      (DeviceArray.numpy()), so the container has to have switched to the host copy itself
+    from pysp_amd.raw_hdr import fuse_exposures_from_debayer
+    for duplicate in (copy.copy, copy.deepcopy, lambda o: pickle.loads(pickle.dumps(o))):
+        exps = []
+        for k in range(2):
+            e = RawRggbBayerData(bay * np.float32(0.5 ** k), wbobj, 10.0 + k, 1.0).demosaic(QualityDemosaic.Fast)
+            e.mat_xyz = wbobj.get_matrix()
+            exps.append(e)
+        dup = duplicate(exps[1])
+        assert exps[1]._dev is None and isinstance(exps[1]._img, np.ndarray)       # no dangling released buffer
+        exps[1].wb_undo(); exps[1].wb_apply()                                    # used to raise ValueError('device copy ... released')
+        fused, count = fuse_exposures_from_debayer(exps)                         # used to fail with AttributeError on exposure 2
+        clean = [RawRggbBayerData(bay * np.float32(0.5 ** k), wbobj, 10.0 + k, 1.0).demosaic(QualityDemosaic.Fast) for k in range(2)]
+        for c in clean:
+            c.mat_xyz = wbobj.get_matrix()
+        clean[1].wb_undo(); clean[1].wb_apply()
+        fused2, count2 = fuse_exposures_from_debayer(clean)
+        assert np.array_equal(np.asarray(fused), np.asarray(fused2), equal_nan=True) and np.array_equal(count, count2)
+        assert np.array_equal(dup.image, np.asarray(RawRggbBayerData(bay * np.float32(0.5), wbobj, 11.0, 1.0).demosaic(QualityDemosaic.Fast).image))
+    # (3c) two threads materialising ONE lazy array at the same moment get the same ndarray (download + release is one step under the context's lock)
+    lin = fresh()
+    got, go = [], threading.Barrier(2)
+
+    def racer():
+        go.wait()
+        got.append(lin.numpy())
+    ts = [threading.Thread(target=racer) for _ in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert len(got) == 2 and got[0] is got[1] and np.array_equal(got[0], ref)
     for f in (copy.copy, copy.deepcopy, pickle.dumps):
         with pytest.raises(TypeError):
             f(_lib.default_context())

@@ -48,6 +48,24 @@ def call_inputs():
     fine = (rng.random((128, 128, 3), dtype=np.float32) * np.float32(0.02) + np.float32(0.2)).astype(np.float32)   # neighbours a few 1e-3 apart: the vote's regime
     inp["lab_lin"] = np.ascontiguousarray(lin); inp["lab_hdr_tonemapped"] = np.ascontiguousarray(linh / (1 + linh))
     inp["lab_cube"] = cube; inp["lab_grey"] = np.ascontiguousarray(grey); inp["lab_fine"] = fine
+    # (round 4) the 33^3 grid NODES: input (p/32, q/32, r/32) for the node [r][q][p] ([B][G][R] order).  cvRound(p/32 * 2^14) = 512 p exactly, so the cell is p and
+    # the position inside it 0: seven of the eight trilinear weights vanish and the output IS the table entry -- lab_grid_from_nodes() turns the recorded
+    # float output back into OpenCV's int16 table, which pysp_ctx_set_lab_lut / oracle.set_cv410_lut / cv2_restated.set_cv410_lab_lut then take as data.
+    g = np.arange(33, dtype=np.float32) / np.float32(32)
+    Bn, Gn, Rn = np.meshgrid(g, g, g, indexing="ij")
+    inp["lab_nodes"] = np.ascontiguousarray(np.stack([Rn, Gn, Bn], axis=-1).reshape(33 * 33, 33, 3))
+    # cell boundaries and cvRound ties: v = (n + 1/2) / 2^14 is exact in float32 and lands on the tie of cvRound(v * 2^14) (round half to even);
+    # n around multiples of 512 (a cell edge) and of 32 (a weight step), plus the float32 neighbours of every such value
+    ns = np.unique(np.concatenate([(512 * np.arange(33)[:, None] + np.arange(-3, 4)[None, :]).ravel(), (32 * np.arange(0, 513, 37)[:, None] + np.arange(-2, 3)[None, :]).ravel()]))
+    ns = ns[(ns >= 0) & (ns <= 16384)]
+    ties = np.concatenate([(ns + d) / 16384.0 for d in (0.0, 0.5, 0.25, 0.75)]).astype(np.float32)
+    ties = np.unique(np.concatenate([ties, np.nextafter(ties, np.float32(2)), np.nextafter(ties, np.float32(-1))]))
+    ties = ties[(ties >= 0) & (ties <= 1)]
+    sweep = np.full((3 * len(ties) + 4096, 3), np.float32(0.40625), np.float32)          # 13/32: a node, so the two fixed channels add no weight structure
+    for c in range(3):
+        sweep[c * len(ties):(c + 1) * len(ties), c] = ties
+    sweep[3 * len(ties):] = ties[rng.integers(0, len(ties), (4096, 3))]                  # all three channels on ties / edges at once
+    inp["lab_sweep"] = np.ascontiguousarray(sweep[None])
     inp["vote_map"] = rng.integers(0, 10, (H, W)).astype(np.float32)
     inp["chroma_diff"] = np.ascontiguousarray(g8["ahd0"][..., 0] - g8["ahd0"][..., 1])
     inp["quarter_rgb"] = np.ascontiguousarray(np.stack([r, (g1 + g2p) / 2, b], axis=-1))
@@ -60,6 +78,24 @@ def call_inputs():
     return inp, (H, W)
 
 
+LAB_INPUTS = ("lab_lin", "lab_hdr_tonemapped", "lab_cube", "lab_grey", "lab_fine", "lab_nodes", "lab_sweep")
+
+
+def lab_grid_from_nodes(nodes_out):
+    """OpenCV's int16 table from the recorded cvtColor output at the grid nodes: (33*33, 33, 3) float32 -> ((33,33,33,3) int16, exact?).
+    In the LUT path L = l * (100 / 2^14) and a = a' * (256 / 2^14) - 128 with integers l, a': the inversion is exact, and `exact` says whether the
+    recorded floats really are such values (False means real cv2 took another path -- IPP, or the non-interpolated one -- and the closed form
+    restatement is the candidate instead)."""
+    o = np.asarray(nodes_out, dtype=np.float64).reshape(33, 33, 33, 3)
+    q = np.stack([o[..., 0] * (16384.0 / 100.0), (o[..., 1] + 128.0) * 64.0, (o[..., 2] + 128.0) * 64.0], axis=-1)
+    grid = np.rint(q).astype(np.int64)
+    back = np.stack([(grid[..., 0].astype(np.float32) * np.float32(100.0 / 16384.0)),
+                     (grid[..., 1].astype(np.float32) * np.float32(256.0 / 16384.0) - np.float32(128.0)),
+                     (grid[..., 2].astype(np.float32) * np.float32(256.0 / 16384.0) - np.float32(128.0))], axis=-1)
+    exact = bool(np.array_equal(back, np.asarray(nodes_out, dtype=np.float32).reshape(33, 33, 33, 3))) and bool((grid >= 0).all() and (grid <= 32767).all())
+    return grid.clip(0, 32767).astype(np.int16), exact
+
+
 def record_calls(cv2):
     inp, (H, W) = call_inputs()
     out = {}
@@ -69,7 +105,7 @@ def record_calls(cv2):
     out["cmb_1010"] = cv2.copyMakeBorder(b, 1, 0, 1, 0, cv2.BORDER_REFLECT)
     out["gauss"] = cv2.GaussianBlur(inp["green_full"], (3, 3), 1.0)
     out["filter2d"] = np.stack([cv2.filter2D(r, -1, k) for k in inp["kernels"]])
-    for k in ("lab_lin", "lab_hdr_tonemapped", "lab_cube", "lab_grey", "lab_fine"):
+    for k in LAB_INPUTS:
         out[k + "_out"] = cv2.cvtColor(inp[k], cv2.COLOR_RGB2LAB)
     out["blur"] = cv2.blur(inp["vote_map"], (3, 3))
     out["median5"] = cv2.medianBlur(inp["chroma_diff"], 5)
