@@ -40,7 +40,8 @@ MAX_CLOCK_HZ = 2.4e9           # MI355X_MICROARCH.md chip table; the VALU bound 
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs, one wave64 VALU instruction issues over >= 2 cycles on a SIMD
 ALG_BYTES_PER_PX = 16          # the fused path: 4 B mosaic read + 12 B RGB written
 # per kernel: the select kernel reads the mosaic and writes RGB, a median stage reads and writes RGB
-KERNEL_ALG_BYTES_PER_PX = {"k_ahd_select": 16, "k_ahd_median_stage": 24, "k_eag": 16, "k_draft": 16, "k_warp_remap": 24}
+KERNEL_ALG_BYTES_PER_PX = {"k_ahd_select": 16, "k_ahd_median_stage": 24, "k_ahd_fused": 40,   # fused = select of one frame + median stage of the previous one
+                           "k_eag": 16, "k_draft": 16, "k_warp_remap": 24}
 
 WORKLOADS = {
     # name: (H, W, quality, stages, description[, tail])   tail: 2 = to_lin_srgb + lin_srgb_to_srgb (default), 1 = to_lin_srgb only
@@ -57,6 +58,9 @@ WORKLOADS = {
     "fuse45": (5464, 8192, -1, 0, "raw_hdr fuse_exposures_to_raw, 7 x 45MP exposures -> HDR mosaic + count (36 B per output px)"),
     "warp100": (8736, 11648, -2, 0, "100MP RGB, DNG WarpRectilinear per-channel Lanczos-4 remap (24 B/px)"),
     # whole BASELINE configs across the GPUs of a node
+    # the headline path on a batch: frames are independent, so the select tiles of frame i + 1 share a grid with the median tiles of frame i (role-interleaved
+    # launch, pysp_pipeline_batch_dev): one step = `--frames` distinct 24 MP frames in, as many sRGB frames out, one C-ABI call
+    "ahd24b": (4000, 6000, 2, 1, "batch of 24MP RGGB frames per step, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb, one batched call (select of frame i+1 and median stage of frame i share a grid)"),
     "cfg3": (4000, 6000, 1, 0, "BASELINE config 3: batch of 64 x 24MP frames per 8 GPUs (8 frames per rank per step), EAG + WB + 3x3 CCM, frame-sharded, RCCL parameter broadcast per batch", 1),
     "cfg5": (8736, 11648, 2, 3, "BASELINE config 5: one 100MP frame per step, AHD (postprocess_stages=3) + WarpRectilinear, horizontal bands over the GPUs, RCCL exchange of the warp's source rows", 0),
 }
@@ -82,6 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (under a launcher): exercises the RCCL broadcast / all_reduce / barrier code path on one GPU")
+    ap.add_argument("--frame-size", default=None, metavar="HxW",
+                    help="REHEARSAL ONLY: run the workload on a smaller frame (even H and W), e.g. to walk the whole N-rank cfg5 path with many ranks sharing one GPU; "
+                         "the line then says config.rehearsal_frame_size and its value is not a benchmark number")
     ap.add_argument("--settle", type=float, default=0.4,
                     help="seconds of untimed steps run BEFORE the W warmup steps so that the clocks have reached their loaded state when a short "
                          "(e.g. 20-step) timed region starts; 0 disables.  The timed region is exactly K steps either way")
@@ -149,6 +156,10 @@ def main() -> None:
 
     H, W, quality, stages, desc = WORKLOADS[args.workload][:5]
     tail = WORKLOADS[args.workload][5] if len(WORKLOADS[args.workload]) > 5 else 2
+    if args.frame_size:
+        H, W = (int(v) for v in args.frame_size.lower().split("x"))
+        if H < 8 or W < 8 or H % 2 or W % 2:
+            sys.exit("--frame-size: even H and W of at least 8")
     mp_per_frame = H * W / 1e6
 
     # ---- shared parameters: rank 0 owns the camera metadata; everyone receives the 96-byte block over RCCL/xGMI.
@@ -173,7 +184,8 @@ def main() -> None:
         w, m = share_params()
         state.update(wb=_lib.wb3(w), M=_lib.mat9(m), wb_np=w, M_np=m)
 
-    n_streams = max(1, args.streams) if args.workload not in ("cfg3", "cfg5") else 1
+    batched = args.workload in ("cfg3", "ahd24b")               # one batched C-ABI call per step over `--frames` resident frames
+    n_streams = max(1, args.streams) if args.workload not in ("cfg3", "cfg5", "ahd24b") else 1
     ctxs = [_lib.Context(dev_index) for _ in range(n_streams)]   # own HIP streams; kernels are timed with events on THOSE streams
     ctx = ctxs[0]
     for c in ctxs:
@@ -186,9 +198,10 @@ def main() -> None:
     extra_cfg = {}
     kernel_ctx = ctx                                              # the context whose per-kernel event pairs are read
 
-    if args.workload == "cfg3":
+    if batched:
         from pysp_amd.pipeline import DevicePipeline
         pipe = DevicePipeline(dev_index)
+        pipe.ctx.set_lab_mode(args.lab_mode)
         kernel_ctx = pipe.ctx
         nf = args.frames
         frames_per_step = nf
@@ -196,9 +209,12 @@ def main() -> None:
         outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(nf)]
         extra_cfg = {"frames_per_rank_per_step": nf, "frames_per_step_total": nf * world, "param_broadcast": "once per step (batch), inside the timed region"}
 
+        def compute(i: int) -> None:                       # the step's work without its collective (what rank 0 repeats alone when it verifies)
+            pipe.batch(frames, state["wb_np"], state["M_np"], quality, False, stages, tail, outs)
+
         def step(i: int) -> None:
             refresh_params()
-            pipe.batch(frames, state["wb_np"], state["M_np"], quality, False, 0, tail, outs)
+            compute(i)
     elif args.workload == "cfg5":
         from pysp_amd.multi_gpu import PHASES, BandPlan, demosaic_warp_banded_dev
         from pysp_amd.pipeline import DevicePipeline
@@ -237,19 +253,23 @@ def main() -> None:
             sat = (ctypes.c_float * 4)(15871.0, 15871.0, 15871.0, 15871.0)
             alg_bytes_per_px = 14
 
-            def step(i: int) -> None:
+            def compute(i: int) -> None:
                 f = frames[i % len(frames)]
                 s = i % n_streams
                 _lib.check(L.pysp_pipeline_u16_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, black, sat, state["wb"], state["M"], quality, 0, stages, tail,
                                                    ctypes.c_void_p(outs[s].data_ptr())))
+            step = compute
         else:
-            def step(i: int) -> None:
-                if share_every and i % share_every == 0:
-                    refresh_params()
+            def compute(i: int) -> None:
                 f = frames[i % len(frames)]
                 s = i % n_streams                       # frame i runs on stream s, writing that stream's output buffer
                 _lib.check(L.pysp_pipeline_dev(ctxs[s].handle, ctypes.c_void_p(f.data_ptr()), H, W, state["wb"], state["M"], quality, 0, stages, tail,
                                                ctypes.c_void_p(outs[s].data_ptr())))
+
+            def step(i: int) -> None:
+                if share_every and i % share_every == 0:
+                    refresh_params()
+                compute(i)
     elif quality == -1:
         K = 7
         base = rggb_frame(H, W, 1000 + rank, scale=8.0, clip_hi=False)
@@ -289,17 +309,15 @@ def main() -> None:
 
     # ---- untimed: bring the clocks to their loaded state (a 20-step timed region is 15 ms of GPU time, shorter than the ramp),
     # then the W warmup steps the caller asked for
+    # (one rule at every N: a COUNT of steps derived from --settle at ~1 ms per 30 MP, so that the N = 1 point of a scaling run warms up exactly like
+    # the N > 1 points -- round 3 settled by wall time at N = 1 and by count at N > 1)
     settle_steps = 0
-    if args.settle > 0 and dist is None:                          # N = 1 only: at N > 1 every rank would have to agree on a count
-        t_end = time.perf_counter() + args.settle
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                step(settle_steps); settle_steps += 1
-            ctx.sync(); torch.cuda.synchronize()
-    elif args.settle > 0:
-        settle_steps = max(1, int(round(args.settle / 1e-3 / max(1.0, mp_per_frame * frames_per_step / 30.0))))   # ~1 ms per 30 MP: same count on every rank
+    if args.settle > 0:
+        settle_steps = max(1, int(round(args.settle / 1e-3 / max(1.0, mp_per_frame * frames_per_step / 30.0))))
         for i in range(settle_steps):
             step(i)
+            if i % 64 == 63:
+                ctx.sync(); torch.cuda.synchronize()                # keep the launch queue short
     for i in range(args.warmup):
         step(i)
     fence()
@@ -432,24 +450,44 @@ def main() -> None:
                             step_ms_at_2cycle_issue=round(ideal_ms, 4), step_frac_of_2cycle_issue=round(ideal_ms / (ms_per_step / frames_per_step), 4))
         except (OSError, ValueError, AttributeError, KeyError, TypeError):
             pass
-        achieved = alg_bytes / (per_kernel[dom] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_stale": traffic_stale,
+        k_achieved = alg_bytes / (per_kernel[dom] * 1e-3) / 1e9
+        # the STEP: the path's algorithmic bytes of one whole step (16 B per output pixel for the fused Bayer -> sRGB path) over the step time, per GPU
+        step_bytes = alg_bytes_per_px * units_per_step * 1e6 / world
+        step_achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
+        step_traffic = None
+        try:
+            step_traffic = sum(float(tj[k]["hbm_bytes"]) * launches[k] / max(1, sample_steps) for k in per_kernel if k in tj and tj[k].get("hbm_bytes")) * frames_per_step or None
+        except Exception:
+            step_traffic = None
+        roofline = {"bound": "hbm", "scope": "step: every kernel of the path, the path's algorithmic bytes (alg_bytes_per_px x pixels of one step) over the step time",
+                    "achieved": round(step_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_achieved / HBM_PEAK_GBS, 5),
+                    "traffic": step_traffic, "traffic_stale": traffic_stale, "alg_bytes_per_step": step_bytes, "alg_bytes_per_px": alg_bytes_per_px,
+                    # the dominant kernel's own figure (its own algorithmic bytes per launch over its own average launch time, HIP events on the launch stream)
+                    "kernel": dom,
+                    "dominant_kernel": {"kernel": dom, "achieved": round(k_achieved, 2), "frac": round(k_achieved / HBM_PEAK_GBS, 5), "alg_bytes_per_launch": alg_bytes,
+                                        "alg_bytes_per_px": kb, "avg_launch_ms": round(per_kernel[dom], 4), "traffic": traffic},
                     # flat copies of the VALU account of the dominant kernel (the nested object `valu` below carries every kernel)
                     "valu_insts_per_px": valu["insts_per_px"] if valu else None, "valu_cycles_per_inst": valu["cycles_per_inst"] if valu else None,
                     "valu_frac_of_2cycle_issue": valu["frac_of_2cycle_issue"] if valu else None,
                     "step_frac_of_2cycle_issue": valu["step_frac_of_2cycle_issue"] if valu else None, "lib_sha256": lib_sha,
-                    "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(per_kernel[dom], 4),
+                    "avg_launch_ms": round(per_kernel[dom], 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
-                    "alg_bytes_per_px": kb,
-                    "pipeline_frac": round(alg_bytes_per_px * units_per_step * 1e6 / (ms_per_step * 1e-3) / 1e9 / (world * HBM_PEAK_GBS), 5),
+                    "pipeline_frac": round(step_achieved / HBM_PEAK_GBS, 5),
                     "valu": valu,
-                    "note": "pipeline_frac = the path's algorithmic bytes of one whole step over the step time and the aggregate HBM peak of the GPUs used; valu = wave-level VALU instructions per launch (PMC, profiles/) "
-                            "spread over the chip's 1024 SIMDs at 2.4 GHz against the 2-cycle issue rate of a wave64 instruction: the AHD kernels are bound by VALU issue, not by HBM"}
+                    "note": "frac = the step-level fraction (round 4; until round 3 `frac` was the dominant kernel's own, now under dominant_kernel); valu = wave-level VALU instructions per launch (PMC, "
+                            "profiles/) spread over the chip's 1024 SIMDs at 2.4 GHz against the 2-cycle issue rate of a wave64 instruction: the AHD kernels are bound by VALU issue, not by HBM"}
 
     cpu_baseline = None
     verify = None
-    if world == 1 and not args.no_cpu_baseline and quality >= 0 and args.workload != "cfg5":
+    def local_fence() -> None:                              # rank 0 alone (the other ranks have left): no barrier
+        for c in ctxs:
+            c.sync()
+        kernel_ctx.sync()
+        torch.cuda.synchronize()
+
+    # cpu_baseline: N = 1 only (a reported baseline, bounded sample).  verify: at every N -- at N > 1 rank 0 repeats the timed call for ONE of its frames without
+    # the collective and compares it with the oracle, so that a multi-GPU line carries parity evidence too (round 3: N = 1 only)
+    if not args.no_cpu_baseline and quality >= 0 and args.workload != "cfg5":
         try:
             from oracle import oracle
             Mo = p[3:].reshape(3, 3)
@@ -457,9 +495,9 @@ def main() -> None:
             u16 = args.workload.endswith("u16")
             done, dt = 0, 0.0
             ver = {"frames": 0, "max_ulp": 0, "values": 0, "nonzero_ulp": 0}
-            if args.workload == "cfg3":              # one batch call fills outs[0..nf-1]
-                step(0)
-                fence()
+            if batched:                              # one batch call fills outs[0..nf-1]
+                compute(0)
+                local_fence()
             for fi, f in enumerate(frames):          # bounded sample: whole resident frames until about 10 s of CPU work are spent
                 sample = np.ascontiguousarray(f.cpu().numpy())
                 if u16:
@@ -479,18 +517,18 @@ def main() -> None:
                 # ---- verify: the very call of the timed region (same entry point, same whole-frame launch, same frame, same output
                 # buffer) once more, downloaded and compared with the oracle's result for that frame, value by value
                 if True:
-                    if args.workload != "cfg3":
-                        step(fi)
-                        fence()
-                    got = (outs[fi] if args.workload == "cfg3" else outs[fi % n_streams]).cpu().numpy()
+                    if not batched:
+                        compute(fi)
+                        local_fence()
+                    got = (outs[fi] if batched else outs[fi % n_streams]).cpu().numpy()
                     n_bad, worst = ulp_compare(np, got, ref)
                     ver["frames"] += 1; ver["values"] += got.size; ver["nonzero_ulp"] += n_bad; ver["max_ulp"] = max(ver["max_ulp"], worst)
                     del got
                 del ref
-                if dt > 10.0:
+                if dt > 10.0 or world > 1:
                     break
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-            cpu_baseline = {"value": round(done * H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": oracle.threads(), "kind": "port",
+            cpu_baseline = None if world > 1 else {"value": round(done * H * W / 1e6 / dt, 3), "unit": "MP/s", "cores": oracle.threads(), "kind": "port",
                             "cores_available": os.cpu_count(), "cores_in_affinity_mask": avail, "threads_used": oracle.threads(), "thread_cap": oracle.thread_cap_reason(),
                             "sample": f"{done} whole frame(s) of the benchmark ({H}x{W}), {dt:.1f} s, oracle/pysp_oracle.c, OpenMP team of {oracle.threads()} "
                                       f"({oracle.thread_cap_reason()}; os.cpu_count() = {os.cpu_count()}), same path"}
@@ -503,7 +541,7 @@ def main() -> None:
                     raw_ref = oracle.demosaic_ahd(np.ascontiguousarray(frames[0].cpu().numpy()), wbo, Mo, False, stages)
                     _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(frames[0].data_ptr()), H, W, state["wb"], state["M"], quality, 0, stages, 0,
                                                    ctypes.c_void_p(outs[0].data_ptr())))
-                    fence()
+                    local_fence()
                     nb, _w = ulp_compare(np, outs[0].cpu().numpy(), raw_ref)
                     verify["bit_exact_demosaic"] = nb == 0
                     del raw_ref
@@ -516,6 +554,8 @@ def main() -> None:
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"
                         else "frame-parallel, no data-path collective; WB/CCM block broadcast from rank 0 (RCCL) per batch")}
     cfg.update(extra_cfg)
+    if args.frame_size:
+        cfg["rehearsal_frame_size"] = f"{H}x{W} (not the workload's own size: the value is not a benchmark number)"
     line = {
         "metric": "megapixels/sec AHD debayer+cam->sRGB, 24MP RGGB" if args.workload == "ahd24" else f"megapixels/sec {args.workload}",
         "value": round(value, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -530,8 +570,10 @@ def main() -> None:
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    if verify is not None and verify["max_ulp"] > 1:
-        sys.stderr.write(f"bench.py: GPU output differs from the oracle by {verify['max_ulp']} ULP (> 1) -- parity broken\n")
+    # every workload verified above is documented as BIT-exact against the oracle: any differing value fails the run (the gate
+    # used to let a 1-ULP regression through with exit code 0)
+    if verify is not None and not (verify["bit_exact"] and verify.get("bit_exact_demosaic", True)):
+        sys.stderr.write(f"bench.py: GPU output differs from the oracle on {verify['frac_nonzero_ulp']:.3g} of the values, by up to {verify['max_ulp']} ULP -- parity broken\n")
         sys.exit(3)
 
 

@@ -19,8 +19,11 @@
  *              (opencv_python==4.10.0.84 is not installed and cannot be installed).  Their
  *              semantics are restated below from OpenCV's documented behaviour; float rounding
  *              order inside cv2 (IPP/AVX dispatch) is unknowable here.  cv2.cvtColor(RGB2LAB) in
- *              particular is restated as closed-form sRGB-decode + D65 CIELab with our own
- *              deterministic pow/cbrt (rgb2lab_px below), not OpenCV's LUT path.
+ *              particular exists as two restatements: lab mode 1 (DEFAULT since round 2, in the
+ *              oracle as in the product) is OpenCV 4.10's LUT + fixed-point trilinear path
+ *              (rgb2lab_px_cv410 below; its 33^3 table is data since round 4: orc_set_cv410_lut);
+ *              lab mode 0 is the closed-form sRGB-decode + D65 CIELab with our own deterministic
+ *              pow / cbrt (rgb2lab_px), round 1's metric, still selectable (orc_set_lab_mode).
  */
 #include <math.h>
 #include <stdint.h>

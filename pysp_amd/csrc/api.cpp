@@ -703,6 +703,25 @@ int pysp_pipeline_batch_dev(pysp_ctx* ctx, const float* const* d_bayers, int n_f
     CTX_ENTER(ctx);
     if (n_frames < 0 || (n_frames > 0 && (!d_bayers || !d_outs))) return fail(PYSP_EBADARG, "pipeline_batch: bad frame list");
     if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_batch: tail must be 0..3");
+    // AHD with one median stage (the README recipe, BASELINE configs[1]): frames are independent, so the select tiles of frame i + 1 can share a grid with the
+    // median tiles of frame i (launch_ahd_pipelined): n + 1 launches, the two instruction mixes resident on every SIMD together.  Built, bit-exact, measured on
+    // MI355X in round 4 and NOT faster (0.616 against 0.611 ms per 24 MP frame, profiles/r4_ab_role_interleaved_batch.log: what the two mixes overlap is lost again
+    // to the fused kernel's five workgroups per CU): OFF unless PYSP_ROLE_INTERLEAVE=1, kept for the record and for the test that pins it
+    const char* ri = getenv("PYSP_ROLE_INTERLEAVE");
+    if (ri && ri[0] == '1' && quality == PYSP_QUALITY_BEST && M && wb && ahd_pipelined_ok(n_frames, H, W, stages, ctx->lab_mode == 1 ? ctx->lablut : nullptr) && even_dims(H, W)) {
+        std::vector<MosaicSrc> srcs((size_t)n_frames);
+        for (int i = 0; i < n_frames; i++) {
+            if (!d_bayers[i] || !d_outs[i]) return fail(PYSP_EBADARG, "pipeline_batch: null frame pointer");
+            srcs[(size_t)i] = mosaic_f32(d_bayers[i]);
+        }
+        float *t0 = nullptr, *t1 = nullptr;
+        const size_t bytes = (size_t)H * W * 12;
+        RESERVE(ctx, S_TMP0, bytes, t0); RESERVE(ctx, S_TMP1, bytes, t1);
+        ctx->tic();
+        LAUNCH_TRY(launch_ahd_pipelined(ctx->stream, srcs.data(), n_frames, H, W, wb, M, hdr != 0, tail, d_outs, t0, t1, ctx->lablut, &ctx->tl));
+        ctx->toc();
+        return PYSP_OK;
+    }
     for (int i = 0; i < n_frames; i++) TRY(run_pipeline_dev(ctx, d_bayers[i], H, W, wb, M, quality, hdr, stages, tail, d_outs[i]));
     return PYSP_OK;
 }

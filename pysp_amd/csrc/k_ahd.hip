@@ -486,33 +486,32 @@ struct AhdParams {
 // Round 2 laid the Lab buffer over the mosaic and horizontal planes (20.6 KB, five workgroups per CU limited by 92 VGPRs): every thread then had to
 // hold the twelve Lab values of its quad across a barrier, and the eight green samples of its window across both directions.  Measured on MI355X
 // (tools/ab_bench.sh, LDS padding): five -> four workgroups per CU costs this kernel 9 %, four -> three 24 %: it is latency-bound, occupancy is the lever.
+// LDS floats of the select tile: the three sections below (+ 2: the last window row of the last Lab plane is read, never used, one row past LPR)
+template <int LAB> struct SelLds {
+    static constexpr bool I16 = LAB == 1 && AHD_I16 != 0;      // packed Lab cells { L, a' | b' << 16 } and integer chroma votes (round 4)
+    static constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GX, NLAB = (I16 ? 2 : 3) * LPR * LPS, N = NMW + NGQ + NLAB + 2;
+};
+// One 28x28 px tile of the select kernel.  The body is a device function so that the stand-alone kernel (k_ahd_select: one tile per workgroup, XCD-aware
+// order) and the role-interleaved kernel (k_ahd_fused: select tiles of one frame and median tiles of the previous one in ONE grid) share it.
+// `planes`: SelLds<LAB>::N floats of LDS, 16-byte aligned; `s_labtab`: LAB_SLOTS float4 of LDS (Lab mode 0 only); `s_nonfinite`: two ints of LDS (HDR only).
 template <bool TINY, bool U16, bool HDR, int LAB, bool TAIL>
-__global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
-    constexpr bool I16 = LAB == 1 && AHD_I16 != 0;      // packed Lab cells { L, a' | b' << 16 } and integer chroma votes (round 4)
-    constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GX, NLAB = (I16 ? 2 : 3) * LPR * LPS;
+DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, float* const planes, float4* const s_labtab, int* const s_nonfinite) {
+    constexpr bool I16 = SelLds<LAB>::I16;
+    constexpr int NMW = SelLds<LAB>::NMW, NGQ = SelLds<LAB>::NGQ;
     static_assert(NMW % 4 == 0 && NGQ % 4 == 0, "16-byte aligned sections");
-    __shared__ __attribute__((aligned(16))) float planes[NMW + NGQ + NLAB + 2];     // + 2: the last window row of the last Lab plane is read (never used) one row past LPR
     float* const mw = planes;
     float* const gq = planes + NMW;
     float* const lab = planes + NMW + NGQ;
     unsigned short* const vmap = reinterpret_cast<unsigned short*>(planes);      // [MPR][MPS] votes h | v << 8, over the dead mosaic planes
     static_assert(MPR * MPS * sizeof(unsigned short) <= NMW * sizeof(float), "the vote map fits over the mosaic planes");
-#ifdef AHD_LDS_PAD
-    __shared__ float s_pad[AHD_LDS_PAD / 4];                                 // experiment: occupancy probe (LDS-limited workgroups per CU)
-    if (p.H < 0) s_pad[threadIdx.x] = 1.0f;
-#endif
-    __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 1];                    // 12 KB of closed-form tables (Lab mode 0 only; mode 1 reads its grid from L2)
     // HDR metric only: did this workgroup write a non-finite L (= luma, ahd.py:55,59) into the Lab buffer of direction H / V?  Only then do the votes need their
     // literal nine-cell form; every other workgroup takes the fast form, whose shortcuts hold for finite values (round 3: 2 642 -> about 2 400 executed instructions)
-    __shared__ int s_nonfinite[HDR ? 2 : 1];
     const LabTab lt{s_labtab, s_labtab + LAB_DEC_SLOTS};
 
     const int tid = threadIdx.x;
     AHD_STAMP(0);
     if (HDR && tid < 2) s_nonfinite[tid] = 0;                                   // (the first barrier below orders it before any P2)
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const double* M = p.ccm.m;
     // the whole halo-3 neighbourhood of the tile lies inside the image: no border rule applies anywhere in P0/P1
@@ -746,23 +745,41 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
             // Lab mode 1, packed cells: integer chroma vote on the whole window; a wave in which some pixel's chroma lies 64 Lab units or more from a direction
             // neighbour's (ec >= 2^24: float32 rounding of the squares could then matter) recomputes its distances in float32 arithmetic on the same window
             auto votes_pk = [&]() {
-                float wl[4][4]; unsigned wc[4][4], ec[4], pc[6];
-                bool exact;                                                     // uniform over the wave
-                auto piece = [&](auto DIRC, auto K0C) {
-                    constexpr int D = decltype(DIRC)::value, K0 = decltype(K0C)::value;
-                    vote_eps_pk<D, K0, K0 + 2>(wc, ec, pc);
-                    exact = __builtin_amdgcn_ballot_w64((ec[K0] | ec[K0 + 1]) >= (1u << 24)) == 0 && (K0 == 0 || exact);   // (piece 2's pair table comes from piece 1's integer form)
-                    if (exact) vote_cells_pk<D, K0, K0 + 2>(wl, wc, ec, pc, cnt);
-                    else {
-                        const unsigned pk = vote_quad_pk_f32<D, K0, K0 + 2>(wl, wc);
-                        cnt[K0] = (int)((pk >> (4 * K0)) & 15u); cnt[K0 + 1] = (int)((pk >> (4 * K0 + 4)) & 15u);
-                    }
-                };
-                load_labrows_pk<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
-                if (dir == 0) piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); else piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-                __builtin_amdgcn_sched_barrier(0);
-                load_labrows_pk<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
-                if (dir == 0) piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}); else piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                // optimistic: the integer form runs straight through (no branch in front of it -- a guard per window piece cost the kernel 7 %, A/B in
+                // profiles/r4_ab_select_i16_guard_and_occupancy.log), the four epsilon distances are ORed on the way, and ONE wave-uniform test at the end
+                // sends a wave that held a distance >= 2^24 through the exact float form, which overwrites the counts
+                unsigned long long big;
+                {
+                    float wl[4][4]; unsigned wc[4][4], ec[4], pc[6];
+                    load_labrows_pk<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
+                    if (dir == 0) { vote_eps_pk<0, 0, 2>(wc, ec, pc); vote_cells_pk<0, 0, 2>(wl, wc, ec, pc, cnt); }
+                    else { vote_eps_pk<1, 0, 2>(wc, ec, pc); vote_cells_pk<1, 0, 2>(wl, wc, ec, pc, cnt); }
+                    const unsigned long long big0 = __builtin_amdgcn_ballot_w64(ec[0] >= (1u << 24)), big1 = __builtin_amdgcn_ballot_w64(ec[1] >= (1u << 24));
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_labrows_pk<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
+                    if (dir == 0) { vote_eps_pk<0, 2, 4>(wc, ec, pc); vote_cells_pk<0, 2, 4>(wl, wc, ec, pc, cnt); }
+                    else { vote_eps_pk<1, 2, 4>(wc, ec, pc); vote_cells_pk<1, 2, 4>(wl, wc, ec, pc, cnt); }
+                    // only the pixels whose votes are consumed (the tile + 1 px: the vote map's cells) may raise the flag -- the outer pixels of the halo quads
+                    // look at the Lab buffer's guard ring, which nobody writes: left in, their garbage sent EVERY wave through the float form
+                    // (profiles/r4_ab_select_i16_trailing_guard_unmasked.log: +17 %)
+                    const unsigned long long rowT = __builtin_amdgcn_ballot_w64(lqy >= 1), rowB = __builtin_amdgcn_ballot_w64(lqy <= TQY);
+                    const unsigned long long colL = __builtin_amdgcn_ballot_w64(lqx >= 1), colR = __builtin_amdgcn_ballot_w64(lqx <= TQX);
+                    big = (big0 & rowT & colL) | (big1 & rowT & colR) |
+                          (__builtin_amdgcn_ballot_w64(ec[2] >= (1u << 24)) & rowB & colL) | (__builtin_amdgcn_ballot_w64(ec[3] >= (1u << 24)) & rowB & colR);
+                }
+#ifndef AHD_I16_NOGUARD          // (timing experiment only: wrong on hard colour noise)
+                if (big != 0) {          // uniform over the wave; never taken on ordinary content
+                    asm volatile("" ::: "memory");                                     // fresh loads: nothing of the integer form stays live into this path
+                    float wl[4][4]; unsigned wc[4][4];
+                    load_labrows_pk<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
+                    unsigned pk = dir == 0 ? vote_quad_pk_f32<0, 0, 2>(wl, wc) : vote_quad_pk_f32<1, 0, 2>(wl, wc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_labrows_pk<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
+                    pk |= dir == 0 ? vote_quad_pk_f32<0, 2, 4>(wl, wc) : vote_quad_pk_f32<1, 2, 4>(wl, wc);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) cnt[k] = (int)((pk >> (4 * k)) & 15u);
+                }
+#endif
             };
             if constexpr (HDR) {
                 if (literal) {
@@ -839,6 +856,23 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     AHD_STAMP(13);             // P4 done (stores issued)
 }
 
+// TINY: quarter planes narrower than 4 need the general (looping) border functions.
+// HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs registers.
+// TAIL: a colour tail may follow the selection (only when no median stage does); the instance without it is the benchmark's.
+template <bool TINY, bool U16, bool HDR, int LAB, bool TAIL>
+__global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p) {
+    __shared__ __attribute__((aligned(16))) float planes[SelLds<LAB>::N];
+#ifdef AHD_LDS_PAD
+    __shared__ float s_pad[AHD_LDS_PAD / 4];                                 // experiment: occupancy probe (LDS-limited workgroups per CU)
+    if (p.H < 0) s_pad[threadIdx.x] = 1.0f;
+#endif
+    __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 1];                    // 12 KB of closed-form tables (Lab mode 0 only; mode 1 reads its grid from L2)
+    __shared__ int s_nonfinite[2];
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    ahd_select_tile<TINY, U16, HDR, LAB, TAIL>(p, tbx, tby, planes, s_labtab, s_nonfinite);
+}
+
 // ================================================================================================
 // Kernel B: one chroma post-process stage (ahd.py:148-161) + optional colour tail.
 //   r' = med5(r-g)+g ; b' = med5(b-g)+g ; g' = (med5(g-r') + med5(g-b') + r' + b') / 2
@@ -910,16 +944,16 @@ struct MedParams {
 #ifndef MED_MIN_WAVES
 #define MED_MIN_WAVES 1                            // 46.9 KB of LDS: three workgroups per CU, registers are not the limit
 #endif
-__global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedParams p) {
+constexpr int MED_LDS_FLOATS = 3 * B4Y * B4X;
+// One 60x28 px tile of the median stage; a device function for the same reason as ahd_select_tile.  `lds_base`: MED_LDS_FLOATS floats of LDS, 16-byte aligned.
+DEVI void ahd_median_tile(const MedParams& p, const int tbx, const int tby, float* const lds_base) {
     // g, r-g, b-g (halo 4); the second level's inputs g-r', g-b' (halo 2) are laid over r-g, b-g once every thread is done with those:
     // 29.4 KB, five workgroups per CU (the stage loses 16 % from three workgroups per CU to two)
-    __shared__ __attribute__((aligned(16))) float lds[3][B4Y][B4X];
+    float (*const lds)[B4Y][B4X] = reinterpret_cast<float (*)[B4Y][B4X]>(lds_base);
     float (*s_g)[B4X] = lds[0], (*s_drg)[B4X] = lds[1], (*s_dbg)[B4X] = lds[2];
     float *s_d1 = &lds[1][0][0], *s_d2 = &lds[2][0][0];
     static_assert(RY * DST + 4 <= B4Y * B4X, "a difference plane fits in the plane it replaces");
     const int tid = threadIdx.x, H = p.H, W = p.W;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
     const int tx0 = tbx * BTX, ty0 = tby * BTY;
     const unsigned rowbytes = (unsigned)W * 12u;
 
@@ -1127,6 +1161,45 @@ __global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedPar
     }
 }
 
+__global__ void __launch_bounds__(NT_B, MED_MIN_WAVES) k_ahd_median_stage(MedParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[MED_LDS_FLOATS];
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    ahd_median_tile(p, tbx, tby, lds);
+}
+
+// ================================================================================================
+// Role-interleaved kernel (round 4): ONE grid whose workgroups are select tiles of frame i + 1 and median tiles of frame i.
+// Why: the two kernels of the AHD path stress different halves of a SIMD.  k_ahd_select is float32 multiply / add work with integer multiplies in its Lab
+// interpolation, k_ahd_median_stage is 80 % v_min / v_max / v_med3; profiles/r4_ubench_pairs.log: a med3 next to an fma costs 5.0 cycles per pair instead of
+// 2.4 + 4.2 -- min / max / med3 (and compares, conversions, shifts) overlap with full-rate float32 issue, as long as both kinds are resident on the SIMD at
+// the same time.  Back to back, the two kernels never are (round 3's two-stream run could not guarantee it either: six select workgroups fill a CU's LDS).
+// Here the role of a workgroup follows from its index, so every CU holds a fixed mix at all times: of the workgroups an XCD receives (every eighth of the
+// grid), the j-th is a median tile iff floor((j + 1) n_med / n) > floor(j n_med / n) (n = the XCD's select + median tiles): evenly spread, both tile
+// sequences in XCD-contiguous order as in xcd_tile.  Registers and LDS are the maximum of the two roles (the median stage's): five workgroups per CU.
+// Frames are independent, so a batch of n frames takes n + 1 launches: select(0); fused(select(i + 1), median(i)) ...; median(n - 1).
+struct FusedPlan { unsigned sel_gx, sel_n, med_gx, med_n; };
+template <bool U16, bool HDR>
+__global__ void __launch_bounds__(NT_A, 1) k_ahd_fused(AhdParams a, MedParams m, FusedPlan pl) {
+    static_assert(NT_A == NT_B, "one workgroup size for both roles");
+    constexpr int NF = SelLds<1>::N > MED_LDS_FLOATS ? SelLds<1>::N : MED_LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[NF];
+    __shared__ int s_nonfinite[2];
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, j = lin >> 3;
+    const unsigned qs = pl.sel_n >> 3, rs = pl.sel_n & 7u, ns = qs + (xcd < rs ? 1u : 0u), s0 = xcd * qs + (xcd < rs ? xcd : rs);
+    const unsigned qm = pl.med_n >> 3, rm = pl.med_n & 7u, nm = qm + (xcd < rm ? 1u : 0u), m0 = xcd * qm + (xcd < rm ? xcd : rm);
+    const unsigned n = ns + nm;
+    if (j >= n) return;
+    const unsigned before = j * nm / n, upto = (j + 1u) * nm / n;      // median tiles among the XCD's first j / first j + 1 workgroups (uniform: scalar unit)
+    if (upto > before) {
+        const unsigned t = m0 + before, by = t / pl.med_gx;
+        ahd_median_tile(m, (int)(t - by * pl.med_gx), (int)by, smem);
+    } else {
+        const unsigned t = s0 + (j - before), by = t / pl.sel_gx;
+        ahd_select_tile<false, U16, HDR, 1, false>(a, (int)(t - by * pl.sel_gx), (int)by, smem, nullptr, s_nonfinite);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl) {
@@ -1170,6 +1243,53 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
         hipLaunchKernelGGL(k_ahd_median_stage, gb, dim3(NT_B), 0, st, m);
         if (tl) tl->end(st);
         cur = m.out;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// A batch of n frames through AHD with ONE median stage, Lab mode 1, frames of at least 8 x 8 px: n + 1 launches instead of 2 n -- select(frame 0), then
+// n - 1 role-interleaved launches (select tiles of frame i + 1 and median tiles of frame i in one grid, k_ahd_fused), then median(frame n - 1).  The
+// intermediate RGB images alternate between d_tmp0 and d_tmp1.  Same kernels' code, same results as n calls of launch_ahd.
+bool ahd_pipelined_ok(int n, int H, int W, int stages, const void* d_lablut) { return n >= 2 && stages == 1 && d_lablut != nullptr && H / 2 >= 4 && W / 2 >= 4; }
+int launch_ahd_pipelined(hipStream_t st, const MosaicSrc* srcs, int n, int H, int W, const float wb[3], const double M[9], int hdr, int tail,
+                         float* const* d_outs, float* d_tmp0, float* d_tmp1, const void* d_lablut, Timeline* tl) {
+    if (!ahd_pipelined_ok(n, H, W, 1, d_lablut)) return -3;
+    AhdParams a;
+    a.labtab = nullptr;
+    a.lablut = reinterpret_cast<const uint4*>(d_lablut);
+    a.H = H; a.W = W; a.hdr = hdr; a.tail = 0;
+    for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
+    for (int i = 0; i < 9; i++) a.ccm.m[i] = M[i];
+    MedParams m;
+    m.H = H; m.W = W; m.ccm = a.ccm; m.tail = tail;
+    float* bufs[2] = {d_tmp0, d_tmp1};
+    const dim3 ga((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY), gb((W + BTX - 1) / BTX, (H + BTY - 1) / BTY);
+    FusedPlan pl{ga.x, ga.x * ga.y, gb.x, gb.x * gb.y};
+    // the largest share of any XCD decides the grid: XCD 0 owns ceil(n / 8) of each sequence
+    const unsigned per_xcd = (pl.sel_n + 7) / 8 + (pl.med_n + 7) / 8;
+    for (int i = 0; i <= n; i++) {
+        const bool sel = i < n, med = i > 0;
+        bool u16 = false;
+        if (sel) { a.src = srcs[i]; a.out = bufs[i & 1]; u16 = srcs[i].u16 != nullptr; }
+        if (med) {
+            m.in = bufs[(i - 1) & 1]; m.out = d_outs[i - 1];
+            m.vec = !(W & 3) && !((reinterpret_cast<uintptr_t>(m.in) | reinterpret_cast<uintptr_t>(m.out)) & 15);
+        }
+        if (sel && med) {
+            if (tl) tl->begin(st, "k_ahd_fused");
+            if (u16) { if (hdr) hipLaunchKernelGGL((k_ahd_fused<true, true>), dim3(8 * per_xcd), dim3(NT_A), 0, st, a, m, pl); else hipLaunchKernelGGL((k_ahd_fused<true, false>), dim3(8 * per_xcd), dim3(NT_A), 0, st, a, m, pl); }
+            else { if (hdr) hipLaunchKernelGGL((k_ahd_fused<false, true>), dim3(8 * per_xcd), dim3(NT_A), 0, st, a, m, pl); else hipLaunchKernelGGL((k_ahd_fused<false, false>), dim3(8 * per_xcd), dim3(NT_A), 0, st, a, m, pl); }
+            if (tl) tl->end(st);
+        } else if (sel) {
+            if (tl) tl->begin(st, "k_ahd_select");
+            if (u16) { if (hdr) hipLaunchKernelGGL((k_ahd_select<false, true, true, 1, false>), ga, dim3(NT_A), 0, st, a); else hipLaunchKernelGGL((k_ahd_select<false, true, false, 1, false>), ga, dim3(NT_A), 0, st, a); }
+            else { if (hdr) hipLaunchKernelGGL((k_ahd_select<false, false, true, 1, false>), ga, dim3(NT_A), 0, st, a); else hipLaunchKernelGGL((k_ahd_select<false, false, false, 1, false>), ga, dim3(NT_A), 0, st, a); }
+            if (tl) tl->end(st);
+        } else {
+            if (tl) tl->begin(st, "k_ahd_median_stage");
+            hipLaunchKernelGGL(k_ahd_median_stage, gb, dim3(NT_B), 0, st, m);
+            if (tl) tl->end(st);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

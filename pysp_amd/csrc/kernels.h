@@ -39,6 +39,12 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut /* Lab mode 1, else NULL */,
                Timeline* tl = nullptr);
 
+// A batch of n frames through AHD with one median stage (Lab mode 1): n + 1 launches, select tiles of frame i + 1 and median tiles of frame i sharing one grid
+// (role-interleaved kernel, k_ahd.hip).  ahd_pipelined_ok says whether the batch qualifies; the caller falls back to n calls of launch_ahd otherwise.
+bool ahd_pipelined_ok(int n, int H, int W, int stages, const void* d_lablut);
+int launch_ahd_pipelined(hipStream_t st, const MosaicSrc* srcs, int n, int H, int W, const float wb[3], const double M[9], int hdr, int tail,
+                         float* const* d_outs, float* d_tmp0, float* d_tmp1, const void* d_lablut, Timeline* tl = nullptr);
+
 // k_eag.hip
 int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
 int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);

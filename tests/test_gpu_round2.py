@@ -311,6 +311,11 @@ def test_bench_default_line_contract():
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["vs_baseline"] is None
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"]
+    # round 4: frac is the STEP's fraction (16 B per output pixel over the step time); the dominant kernel's own figure sits under its own key
+    assert abs(r["achieved"] - 16 * 24e6 / (line["ms_per_step"] * 1e-3) / 1e9) < 0.5 and r["frac"] == r["pipeline_frac"]
+    dk = r["dominant_kernel"]
+    assert dk["kernel"] == r["kernel"] and abs(dk["frac"] - dk["achieved"] / 8000.0) < 1e-4 and dk["frac"] > r["frac"] and dk["avg_launch_ms"] < line["ms_per_step"]
+    assert r["traffic"] > r["alg_bytes_per_step"]
     assert r["valu"] and 0 < r["valu"]["frac_of_2cycle_issue"] <= 1.0 and r["valu"]["insts_per_px"] > 100
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1

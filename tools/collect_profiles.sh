@@ -19,7 +19,9 @@ find "$out/stats" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" 
 echo "stats done"
 # 3. every other workload (one JSON line each)
 : > "$out/workloads.jsonl"
-for w in ahd24u16 eag24 eag24ccm eag24ccmu16 eag24raw draft12 draft12ccm draft12raw fuse45 warp100 cfg3 cfg5; do one --workload $w --no-cpu-baseline >> "$out/workloads.jsonl"; done
+# (the lines of the BASELINE configs and of the uint16 headline carry their own verify block: no --no-cpu-baseline for those -- VERDICT r3 item 6b)
+for w in ahd24b ahd24u16 eag24ccm draft12 cfg3; do one --workload $w >> "$out/workloads.jsonl"; done
+for w in eag24 eag24ccmu16 eag24raw draft12ccm draft12raw fuse45 warp100 cfg5; do one --workload $w --no-cpu-baseline >> "$out/workloads.jsonl"; done
 one --lab-mode closed_form --no-cpu-baseline >> "$out/workloads.jsonl"
 one --gpus 2 --backend gloo --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline >> "$out/workloads.jsonl"
 one --gpus 2 --backend gloo --workload cfg3 --steps 20 --warmup 3 --no-cpu-baseline >> "$out/workloads.jsonl"
