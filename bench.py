@@ -86,6 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (under a launcher): exercises the RCCL broadcast / all_reduce / barrier code path on one GPU")
+    ap.add_argument("--scene", default="synthetic", choices=["synthetic", "noise"],
+                    help="input frames: the SURVEY 8d synthetic scene (default) or pure rng.random noise -- the worst case for the homogeneity vote (every decision is "
+                         "close, and since round 4 hard colour noise sends waves of the select kernel through the exact float form of its chroma distances)")
     ap.add_argument("--frame-size", default=None, metavar="HxW",
                     help="REHEARSAL ONLY: run the workload on a smaller frame (even H and W), e.g. to walk the whole N-rank cfg5 path with many ranks sharing one GPU; "
                          "the line then says config.rehearsal_frame_size and its value is not a benchmark number")
@@ -152,7 +155,11 @@ def main() -> None:
     from pysp_amd import _lib
     from pysp_amd.colorize.transform import final_matrix
     from pysp_amd.multi_gpu import PARAM_DOUBLES, pack_params, unpack_params
-    from pysp_amd.synth import default_wb, rggb_frame
+    from pysp_amd.synth import default_wb, random_frame
+    from pysp_amd.synth import rggb_frame as _scene_frame
+
+    def rggb_frame(h, w, seed, **kw):                           # every workload draws its frames through this: --scene noise swaps the generator
+        return random_frame(h, w, seed) if args.scene == "noise" and not kw else _scene_frame(h, w, seed, **kw)
 
     H, W, quality, stages, desc = WORKLOADS[args.workload][:5]
     tail = WORKLOADS[args.workload][5] if len(WORKLOADS[args.workload]) > 5 else 2
@@ -554,6 +561,8 @@ def main() -> None:
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"
                         else "frame-parallel, no data-path collective; WB/CCM block broadcast from rank 0 (RCCL) per batch")}
     cfg.update(extra_cfg)
+    if args.scene != "synthetic":
+        cfg["scene"] = "pure uniform noise (rng.random), not the SURVEY 8d scene"
     if args.frame_size:
         cfg["rehearsal_frame_size"] = f"{H}x{W} (not the workload's own size: the value is not a benchmark number)"
     line = {

@@ -519,39 +519,55 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
 
     // ---- P0: white-balanced mosaic planes, symmetric (edge-duplicating) reflect per plane (ahd.py:77-80).
     // One 8-byte load per quad row; a thread's loads are all issued before its first LDS store.
+    // Round 4 mapping: the 2 MWY x MWX pairs of the tile as rows of 32 lanes -- lane (r, c) = (tid / 32, tid % 32) takes pair column c (< MWX) of pair rows
+    // r, r + 8, r + 16, ...: no division by MWX, the row's CFA parity (and with it the planes and WB factors) is one per-lane constant, the global address of
+    // row r + 8 k is a uniform base plus ONE per-lane offset, and the LDS addresses differ by immediates.  (Until round 3 element idx = tid + 256 k was split by
+    // idx / MWX per element, and the compiler evaluated the border path's reflections and 64-bit addresses next to the interior path's for every element:
+    // 215 vector instructions before the first barrier, 30 of them of the multiplier family at 6-8 cycles -- profiles/r4_isa_mix_k_ahd_select_f32lab.csv.)
     {
-        constexpr int NPAIR = 2 * MWY * MWX, NL = (NPAIR + NT_A - 1) / NT_A;
+        static_assert(MWX <= 32 && NT_A % 32 == 0, "a pair row fits in 32 lanes");
+        constexpr int RPP = NT_A / 32, NROWS = 2 * MWY, NL = (NROWS + RPP - 1) / RPP;      // pair rows per pass, passes
         constexpr int NTAB = LAB == 0 ? (LAB_SLOTS + NT_A - 1) / NT_A : 0;
+        const int r = tid >> 5, c = tid & 31;
+        const bool on = c < MWX;
+        const int cc = on ? c : MWX - 1;                                     // idle lanes repeat the last column's (valid) address
+        const int dy = r & 1;                                                // RPP is even: every pass of a lane has the same row parity
+        static_assert(RPP % 2 == 0, "row parity is a per-lane constant");
         float2 tmp[NL];
         float4 ttab[NTAB + 1];
 #pragma unroll
         for (int k = 0; k < NTAB; k++) ttab[k] = p.labtab[min(tid + k * NT_A, LAB_SLOTS - 1)];
+        if (!U16 && inside) {     // uniform per workgroup: 64-bit tile origin (scalar) + tile-local 32-bit byte offset per lane
+            const char* const tile = reinterpret_cast<const char*>(p.src.f32 + (size_t)(2 * (tq0y - 3)) * W + 2 * (tq0x - 3));
+            const unsigned rowb = (unsigned)W * 4u;
+            const unsigned voff = mul24((unsigned)r, rowb) + 8u * (unsigned)cc;
 #pragma unroll
-        for (int k = 0; k < NL; k++) {
-            int idx = tid + k * NT_A;
-            if (idx >= NPAIR) idx = NPAIR - 1;
-            int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
-            int qi = tq0y - 3 + my, qj = tq0x - 3 + mx;
-            if (!inside) {                                                     // uniform per workgroup: interior tiles skip the border rules
-                qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
-                qj = TINY ? b_sym(qj, w) : b_sym1(qj, w);
+            for (int k = 0; k < NL; k++) {
+                const int ry = (NROWS % RPP == 0 || r + k * RPP < NROWS) ? k * RPP : 0;   // rows past the tile (other tile shapes only) re-read the lane's first row
+                tmp[k] = *reinterpret_cast<const float2*>(tile + (voff + (unsigned)ry * rowb));             // (scalar base, 32-bit vector offset): one v_add_u32 per pass
             }
-            if (!U16 && inside)     // uniform 64-bit tile origin + tile-local 32-bit byte offset: (scalar base, vector offset) loads
-                tmp[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.src.f32 + (size_t)(2 * (tq0y - 3)) * W + 2 * (tq0x - 3)) +
-                                                          (mul24((unsigned)ry, (unsigned)W * 4u) + 8u * (unsigned)mx));
-            else
+        } else {
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const int ry = min(r + k * RPP, NROWS - 1), my = ry >> 1;
+                int qi = tq0y - 3 + my, qj = tq0x - 3 + cc;
+                if (!inside) {
+                    qi = TINY ? b_sym(qi, h) : b_sym1(qi, h);
+                    qj = TINY ? b_sym(qj, w) : b_sym1(qj, w);
+                }
                 tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy != 0);
-        }
-#pragma unroll
-        for (int k = 0; k < NL; k++) {
-            int idx = tid + k * NT_A;
-            if (idx < NPAIR) {
-                int ry = idx / MWX, mx = idx - ry * MWX, my = ry >> 1, dy = ry & 1;
-                // even row: (R, G1) ; odd row: (G2, B)
-                mw[((dy ? P_G2 : P_R) * MWY + my) * MWX + mx] = tmp[k].x * (dy ? p.wb[1] : p.wb[0]);
-                mw[((dy ? P_B : P_G1) * MWY + my) * MWX + mx] = tmp[k].y * (dy ? p.wb[2] : p.wb[1]);
             }
         }
+        // even row: (R, G1) ; odd row: (G2, B)
+        const float w0 = dy ? p.wb[1] : p.wb[0], w1 = dy ? p.wb[2] : p.wb[1];
+        float* const d0 = mw + ((dy ? P_G2 : P_R) * MWY + (r >> 1)) * MWX + cc;
+        float* const d1 = mw + ((dy ? P_B : P_G1) * MWY + (r >> 1)) * MWX + cc;
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (on && (NROWS % RPP == 0 || r + k * RPP < NROWS)) {
+                d0[k * (RPP / 2) * MWX] = tmp[k].x * w0;
+                d1[k * (RPP / 2) * MWX] = tmp[k].y * w1;
+            }
 #pragma unroll
         for (int k = 0; k < NTAB; k++) if (tid + k * NT_A < LAB_SLOTS) s_labtab[tid + k * NT_A] = ttab[k];
     }

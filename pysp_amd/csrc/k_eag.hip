@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     }
     float hf[4], rr[4], bb[4];
     highpass_quad(Wn, hf);                                           // eag.py:156
+#ifndef EAG_SCALAR_FILTERS
     {
         v2f o2[4];
         filt_base_tl2(wr2, o2);
@@ -182,6 +183,23 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
 #pragma unroll
         for (int k = 0; k < 4; k++) bb[k] = o2[k].y + (o2[k].x + hf[k]);
     }
+#else
+    {   // experiment (round 4): the paired LDS layout with SCALAR filter arithmetic -- v_pk_*_f32 belongs to the multiplier family that costs 5-8 cycles
+        // inside a float32 stream (profiles/r4_ubench_pairs.log); same values, same rounding
+        Win3 wdr, wdb;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { wdr.v[r][c] = wr2.v[r][c].y; wdb.v[r][c] = wb2.v[r][c].y; }
+        float fg[4], fd[4];
+        filt_base_tl(wgr, fg); filt_base_tl(wdr, fd);
+#pragma unroll
+        for (int k = 0; k < 4; k++) rr[k] = fd[k] + (fg[k] + hf[k]);
+        filt_base_br(wgb, fg); filt_base_br(wdb, fd);
+#pragma unroll
+        for (int k = 0; k < 4; k++) bb[k] = fd[k] + (fg[k] + hf[k]);
+    }
+#endif
     float gg[4] = {wgr.v[1][1], g1_c, g2_c, wgb.v[1][1]};
 #pragma unroll
     for (int k = 0; k < 4; k++) {

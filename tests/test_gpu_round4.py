@@ -119,19 +119,20 @@ def _bench(*argv, timeout=900):
     return json.loads(lines[0])
 
 
-def test_bench_cfg5_six_real_ranks_share_the_gpu():
-    """BASELINE config 5's whole N-rank path with SIX real processes (the GPU box admits at most six processes on its card; the judge's eight would trip the
-    process guard) on a reduced frame: bands, per-band demosaic with the 20-row halo, device-side bound of the warp's source rows, all-gather of the bounds,
-    the exchange plan, host-staged row exchange (gloo), banded warp, per-rank statistics -- end to end, as typed, ONE JSON line."""
-    line = _bench("--gpus", "6", "--backend", "gloo", "--workload", "cfg5", "--frame-size", "2184x2912", "--steps", "1", "--warmup", "1", "--settle", "0")
-    assert line["n_gpus"] == 6 and line["scaling"] == "strong" and line["config"]["bands"] == 6 and "rehearsal_frame_size" in line["config"]
+def test_bench_cfg5_four_real_ranks_share_the_gpu():
+    """BASELINE config 5's whole N-rank path with FOUR real processes on a reduced frame (the GPU box admits six processes on its card: the test runner, the
+    launcher's agent and four ranks -- the judge's eight, and six, trip the process guard; the eight-rank geometry itself is covered by the gloo plan test on
+    CPU): bands, per-band demosaic with the 20-row halo, device-side bound of the warp's source rows, all-gather of the bounds, the exchange plan, host-staged
+    row exchange (gloo), banded warp, per-rank statistics -- end to end, as typed, ONE JSON line."""
+    line = _bench("--gpus", "4", "--backend", "gloo", "--workload", "cfg5", "--frame-size", "2184x2912", "--steps", "1", "--warmup", "1", "--settle", "0")
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["config"]["bands"] == 4 and "rehearsal_frame_size" in line["config"]
     rk = line["ranks_ms_per_step"]
-    assert len(rk["per_rank"]) == 6 and all(v > 0 for v in rk["per_rank"])
+    assert len(rk["per_rank"]) == 4 and all(v > 0 for v in rk["per_rank"])
     got, would = rk["exchange_bytes_received_per_rank"], rk["allgather_bytes_received_per_rank_would_be"]
     assert sum(got) == sum(rk["exchange_bytes_sent_per_rank"]) and all(0 < g < w for g, w in zip(got, would))
-    # rows move between neighbouring bands only: an inner band receives from two neighbours, an outer one from one; 364-row bands, Lanczos support + warp reach
+    # rows move between neighbouring bands only: an inner band receives from two neighbours, an outer one from one
     rows = rk["exchange_rows_received_per_rank"]
-    assert all(0 < r <= 120 for r in rows) and rows[0] <= rows[2] and rows[5] <= rows[3]
+    assert all(0 < r <= 120 for r in rows) and rows[0] <= rows[1] and rows[3] <= rows[2]
     assert set(line["phases_ms"]) == {"demosaic", "bound_allgather", "row_exchange", "warp"}
 
 

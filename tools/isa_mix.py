@@ -73,6 +73,26 @@ def classify(op: str) -> str:
     return "int_full" if FULL_RATE_INT.match(op) else "int_half"
 
 
+# Round 4 (tools/ubench_valu4.hip, profiles/r4_ubench_pairs.log): the half-rate instructions are TWO kinds once they sit in a float32 stream.
+#   A  min / max / med3, compares, v_cndmask, conversions, shifts, bfe, addc, perm, three-operand adds: next to an fma they cost 2.2 - 2.7 cycles (pair 4.6 - 5.1),
+#      and in a 3 : 1 mix they vanish (fma, mul, add, X = 8.7 - 8.9 cycles for four instructions);
+#   B  the multiplier family -- v_dot2*, 24-bit and 32-bit integer multiplies / mads, every v_pk_*, all float64: next to an fma they cost 5.3 - 6.0 cycles
+#      (pair 7.7 - 8.4, MORE than the two alone), 8.3 in a 3 : 1 mix (fma, mul, add, dot2 = 15.5), and they do not overlap with min / max / med3 either.
+B_CLASS = re.compile(r"v_(dot\d\w*|mul_u32_u24|mul_i32_i24|mad_u32_u24|mad_i32_i24|mul_lo_u32|mul_hi_u32|mul_hi_i32|mul_lo_i32|mad_u64_u32|mad_i64_i32|pk_\w+)(_e32|_e64)?$")
+
+
+def ab_class(op: str) -> str:
+    """F (full rate), A (cheap half rate), B (multiplier family), T (transcendental) or '' for non-VALU."""
+    c = classify(op)
+    if c not in RATE_OF:
+        return ""
+    if c == "trans":
+        return "T"
+    if c == "f64" or B_CLASS.match(op):
+        return "B"
+    return "F" if RATE_OF[c] == "F" else "A"
+
+
 def kernel_body(asm: str, want: str):
     """[(label or None, opcode)] of the kernel whose demangled symbol contains `want`."""
     syms = re.findall(r"^(_Z\w+):\s*; @", asm, flags=re.M)
@@ -130,21 +150,25 @@ def main() -> None:
                 for k in range(pos[tgt], i + 1):
                     loop[k] = True
     names = [n for n in args.phase_names.split(",") if n]
-    phases, cur, cur_loop = [], dict.fromkeys(CLASSES, 0), 0
+    AB = ["F", "A", "B", "T"]
+    phases, cur, cur_loop = [], dict.fromkeys(CLASSES + AB, 0), 0
     for i, (lab, op, rest) in enumerate(body):
         if not op:
             continue
         c = classify(op)
         cur[c] += 1
+        if ab_class(op):
+            cur[ab_class(op)] += 1
         if loop[i] and c not in ("sync",):
             cur_loop += 1
         if op == "s_barrier":
-            phases.append((cur, cur_loop)); cur, cur_loop = dict.fromkeys(CLASSES, 0), 0
+            phases.append((cur, cur_loop)); cur, cur_loop = dict.fromkeys(CLASSES + AB, 0), 0
     phases.append((cur, cur_loop))
     w = csv.writer(sys.stdout)
     w.writerow(["kernel", sym])
-    w.writerow(["phase"] + CLASSES + ["valu_total", "in_loop", "full_rate", "half_rate", "serial_cycles", "cycles_per_valu_inst", "overlap_bound_cycles"])
-    tot = dict.fromkeys(CLASSES, 0)
+    w.writerow(["phase"] + CLASSES + ["valu_total", "in_loop", "full_rate", "half_rate", "serial_cycles", "cycles_per_valu_inst", "overlap_bound_cycles",
+                                      "F", "A_cheap_half", "B_multiplier_family", "T", "mixed_model_lo_cycles", "mixed_model_hi_cycles", "mixed_lo_per_inst", "mixed_hi_per_inst"])
+    tot = dict.fromkeys(CLASSES + AB, 0)
     valu = tuple(RATE_OF)
 
     def tail(ph):
@@ -152,11 +176,18 @@ def main() -> None:
         nf = sum(ph[c] for c in valu if RATE_OF[c] == "F")
         cf = sum(ph[c] * costs[c] for c in valu if RATE_OF[c] == "F")
         cs = sum(ph[c] * costs[c] for c in valu if RATE_OF[c] != "F")
-        return [nv, None, nf, nv - nf, round(cf + cs, 1), round((cf + cs) / nv, 3) if nv else "", round(max(cf, cs), 1)]
+        # mixed-stream bracket from profiles/r4_ubench_pairs.log: F 2.38; A between 1.7 (3 : 1 mixes) and 2.65 (1 : 1) while there is full-rate work to pair it with,
+        # 4.15 for the excess; B between 6.0 (1 : 1) and 8.3 (3 : 1); T 9.5
+        nF, nA, nB, nT = ph["F"], ph["A"], ph["B"], ph["T"]
+        pa = min(nA, nF)
+        lo = nF * 2.38 + pa * 1.7 + (nA - pa) * 4.15 + nB * 6.0 + nT * 9.5
+        hi = nF * 2.38 + pa * 2.65 + (nA - pa) * 4.15 + nB * 8.3 + nT * 9.5
+        return [nv, None, nf, nv - nf, round(cf + cs, 1), round((cf + cs) / nv, 3) if nv else "", round(max(cf, cs), 1),
+                nF, nA, nB, nT, round(lo, 1), round(hi, 1), round(lo / nv, 3) if nv else "", round(hi / nv, 3) if nv else ""]
     for k, (ph, nl) in enumerate(phases):
         t = tail(ph); t[1] = nl
         w.writerow([names[k] if k < len(names) else f"phase{k}"] + [ph[c] for c in CLASSES] + t)
-        for c in CLASSES:
+        for c in CLASSES + AB:
             tot[c] += ph[c]
     t = tail(tot); t[1] = sum(n for _, n in phases)
     w.writerow(["total"] + [tot[c] for c in CLASSES] + t)
