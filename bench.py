@@ -83,6 +83,9 @@ def parse_args(argv=None):
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo rehearses the N > 1 path with host-staged collectives, ranks may share a GPU)")
     ap.add_argument("--lab-mode", default="cv410_lut", choices=["closed_form", "cv410_lut"],
                     help="restatement of cv2.cvtColor(RGB2LAB) behind AHD's homogeneity vote (pysp_ctx_set_lab_mode)")
+    ap.add_argument("--lab-layout", default="packed", choices=["packed", "planes"],
+                    help="Lab mode 1 inside the AHD select kernel (same results): packed cells + integer chroma votes (default, fastest on ordinary content) or "
+                         "float planes + float votes (round 3's form: content-independent speed)")
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (under a launcher): exercises the RCCL broadcast / all_reduce / barrier code path on one GPU")
@@ -197,6 +200,7 @@ def main() -> None:
     ctx = ctxs[0]
     for c in ctxs:
         c.set_lab_mode(args.lab_mode)
+        c.set_lab_layout(args.lab_layout)
     L = _lib.lib()
     alg_bytes_per_px = ALG_BYTES_PER_PX
     frames_per_step = 1
@@ -209,6 +213,7 @@ def main() -> None:
         from pysp_amd.pipeline import DevicePipeline
         pipe = DevicePipeline(dev_index)
         pipe.ctx.set_lab_mode(args.lab_mode)
+        pipe.ctx.set_lab_layout(args.lab_layout)
         kernel_ctx = pipe.ctx
         nf = args.frames
         frames_per_step = nf
@@ -227,6 +232,7 @@ def main() -> None:
         from pysp_amd.pipeline import DevicePipeline
         pipe = DevicePipeline(dev_index)
         pipe.ctx.set_lab_mode(args.lab_mode)
+        pipe.ctx.set_lab_layout(args.lab_layout)
         kernel_ctx = pipe.ctx
         scaling = "strong"
         plan = BandPlan(H, W, world, rank, stages)
@@ -555,7 +561,7 @@ def main() -> None:
         except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
             cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc!r}"}
 
-    cfg = {"workload": desc, "H": H, "W": W, "lab_mode": args.lab_mode, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
+    cfg = {"workload": desc, "H": H, "W": W, "lab_mode": args.lab_mode, "lab_layout": args.lab_layout, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
            "backend": ("rccl" if args.backend == "nccl" else "gloo") if dist is not None else None,
            "untimed_settle_steps": settle_steps,
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"

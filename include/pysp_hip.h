@@ -81,6 +81,12 @@ int pysp_lab_cv410_lut(int16_t *out);
  * interpolation weight but one is zero there) so that a 1-LSB disagreement becomes a data change.  Waits for the context's stream, then uploads (2.5 MB).
  * pysp_ctx_get_lab_lut copies the table in use into out[33*33*33*3]. */
 int pysp_ctx_set_lab_lut(pysp_ctx *ctx, const int16_t *grid);
+/* How the AHD select kernel keeps the Lab values of mode 1 (a performance choice: both forms return the same bits, debayer/ahd_homogeneity_cython.pyx:47-58):
+ *   0 (default) packed cells { L, a'|b'<<16 }, chroma distances on the table's integers, seven workgroups per CU -- 3 % faster on ordinary content; a wave
+ *               that meets a chroma step of 64 Lab units or more between neighbouring pixels redoes its votes in float32 arithmetic (pure colour noise: +17 %);
+ *   1           three float planes and float votes (round 3's kernel): the same speed on any content. */
+int pysp_ctx_set_lab_layout(pysp_ctx *ctx, int layout);
+int pysp_ctx_get_lab_layout(pysp_ctx *ctx);
 int pysp_ctx_get_lab_lut(pysp_ctx *ctx, int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
@@ -195,11 +201,13 @@ int pysp_pipeline_u16_dev(pysp_ctx *ctx, const uint16_t *d_bayer, int H, int W, 
  * raw_hdr.py:85-158 fuse_exposures_to_raw, pixel loop :135-148.  The host computes, with NumPy as
  * the reference does, ev_off[k] = float32(2**(ev_k-target)) (:119-121), bias[k*4+c] =
  * float32(1.6**(-0.1*|ev_off_k*w_c|)) for CFA site c in r,g1,b,g2 order (:128-136), and
- * kmax = argmax(ev_off) (:143).  out: (H,W) float32; count: (H,W) int32 (:123,:141). */
+ * kmax = argmax(ev_off) (:143).  out: (H,W) float32; count: (H,W) int32 (:123,:141).
+ * Any K >= 1 (as the reference's loop): more than 16 exposures run as passes of 16 in order, the partial sums carried in the
+ * context's workspace -- the same float32 additions in the same order, so the same bits as one pass. */
 int pysp_fuse_raw_f32(pysp_ctx *ctx, const float *const *frames, int K, int H, int W, const float *ev_off, const float *bias, int kmax, float *out, int32_t *count);
 int pysp_fuse_raw_dev(pysp_ctx *ctx, const float *const *d_frames, int K, int H, int W, const float *ev_off, const float *bias, int kmax, float *d_out, int32_t *d_count);
 
-/* raw_hdr.py:7-83 fuse_exposures_from_debayer, pixel loop :54-81, K <= 12 exposures of npx RGB pixels.
+/* raw_hdr.py:7-83 fuse_exposures_from_debayer, pixel loop :54-81, K >= 1 exposures of npx RGB pixels (passes of 16, as above).
  *   coeff[k*3+c] = exposure._wb_coeff, applied[k] = exposure._wb_applied (image_base.py:31,45-60),
  *   bias[k] = float32(1.6**(-0.1*ev_off_k)) (:60-61), kmax = last k with ev_off_k == max (:67-68),
  *   M = final matrix for the trailing cam_to_lin_srgb(clip_highlights=False) (:81) or NULL for none.

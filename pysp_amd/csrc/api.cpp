@@ -64,6 +64,7 @@ struct pysp_ctx {
     float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
     int lab_mode = 1;            // 1 (default): OpenCV 4.10's LUT + trilinear restatement; 0: closed-form Lab (tables above)
     void* lablut = nullptr;      // mode 1: [34][34][34] x 64 B grid (devmath.h)
+    int lab_layout = 0;          // mode 1: 0 packed Lab cells + integer chroma votes (default), 1 float planes + float votes (pysp_ctx_set_lab_layout)
     std::vector<int16_t> lab_grid;   // the 33^3 x 3 grid the device copy was built from (built-in restatement, or injected: pysp_ctx_set_lab_lut)
     Timeline tl;
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
@@ -277,6 +278,13 @@ int pysp_ctx_set_lab_mode(pysp_ctx* ctx, int mode) {
     return PYSP_OK;
 }
 int pysp_ctx_get_lab_mode(pysp_ctx* ctx) { return ctx ? ctx->lab_mode : -1; }
+int pysp_ctx_set_lab_layout(pysp_ctx* ctx, int layout) {
+    CTX_ENTER(ctx);
+    if (layout != 0 && layout != 1) return fail(PYSP_EBADARG, "lab layout must be 0 (packed cells, integer chroma votes) or 1 (float planes, float votes)");
+    ctx->lab_layout = layout;
+    return PYSP_OK;
+}
+int pysp_ctx_get_lab_layout(pysp_ctx* ctx) { return ctx ? ctx->lab_layout : -1; }
 
 int pysp_ctx_set_lab_lut(pysp_ctx* ctx, const int16_t* grid) {
     CTX_ENTER(ctx);
@@ -577,7 +585,7 @@ static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, c
         size_t bytes = (size_t)H * W * 12;
         if (stages >= 1) RESERVE(ctx, S_TMP0, bytes, t0);
         if (stages >= 2) RESERVE(ctx, S_TMP1, bytes, t1);
-        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl));
+        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl, ctx->lab_layout));
     } else if (quality == PYSP_QUALITY_FAST) {
         LAUNCH_TRY(launch_eag(ctx->stream, src, H, W, wb, M, tail, d_out, &ctx->tl));
     } else if (quality == PYSP_QUALITY_DRAFT) {
@@ -790,35 +798,49 @@ int pysp_wb_scale_f32(pysp_ctx* ctx, const float* in, size_t npx, const float co
 }
 
 // ---- HDR raw fusion -----------------------------------------------------------------------------------
+// Any number of exposures (the reference's loops take any; until round 3 this library stopped at 16 / 12): more than one pass worth of them run as passes of
+// fuse_max_exposures_per_pass() in order, partial sums carried in a workspace block -- same float32 additions in the same order, same bits as one pass.
 int pysp_fuse_raw_dev(pysp_ctx* ctx, const float* const* d_frames, int K, int H, int W, const float* ev_off, const float* bias, int kmax, float* d_out, int32_t* d_count) {
     CTX_ENTER(ctx);
     if (!d_frames || !ev_off || !bias || !d_out || !d_count) return fail(PYSP_EBADARG, "fuse_raw: null pointer");
-    if (K < 1 || K > 16) return fail(PYSP_EBADARG, "fuse_raw: 1..16 exposures supported (got %d)", K);
+    if (K < 1) return fail(PYSP_EBADARG, "fuse_raw: at least one exposure (got %d)", K);
     if (!even_dims(H, W) || kmax < 0 || kmax >= K) return fail(PYSP_EBADARG, "fuse_raw: bad shape %dx%d or kmax %d", H, W, kmax);
+    for (int k = 0; k < K; k++)
+        if (!d_frames[k]) return fail(PYSP_EBADARG, "fuse_raw: null frame %d", k);
+    float* part = nullptr;
+    if (K > fuse_max_exposures_per_pass()) RESERVE(ctx, S_TMP0, (size_t)H * W * 4, part);
     ctx->tic();
     ctx->tl.begin(ctx->stream, "k_fuse_raw");
-    LAUNCH_TRY(launch_fuse_raw(ctx->stream, d_frames, K, H, W, ev_off, bias, kmax, d_out, d_count));
+    LAUNCH_TRY(launch_fuse_raw(ctx->stream, d_frames, K, H, W, ev_off, bias, kmax, d_out, d_count, part));
     ctx->tl.end(ctx->stream);
     ctx->toc();
     return PYSP_OK;
 }
 int pysp_fuse_raw_f32(pysp_ctx* ctx, const float* const* frames, int K, int H, int W, const float* ev_off, const float* bias, int kmax, float* out, int32_t* count) {
     CTX_ENTER(ctx);
-    if (!frames || !out || !count) return fail(PYSP_EBADARG, "fuse_raw: null pointer");
-    if (K < 1 || K > 16) return fail(PYSP_EBADARG, "fuse_raw: 1..16 exposures supported (got %d)", K);
+    if (!frames || !out || !count || !ev_off || !bias) return fail(PYSP_EBADARG, "fuse_raw: null pointer");
+    if (K < 1 || kmax < 0 || kmax >= K) return fail(PYSP_EBADARG, "fuse_raw: bad exposure count %d or kmax %d", K, kmax);
     if (!even_dims(H, W)) return fail(PYSP_EBADARG, "fuse_raw: bad shape %dx%d", H, W);
-    size_t N = (size_t)H * W;
-    std::vector<const float*> d_fr(K);
-    if (S_FR0 + K > pysp_ctx::NSLOT) return fail(PYSP_EBADARG, "fuse_raw: too many exposures");
-    for (int k = 0; k < K; k++) {
-        float* d; RESERVE(ctx, S_FR0 + k, N * 4, d);
+    for (int k = 0; k < K; k++)
         if (!frames[k]) return fail(PYSP_EBADARG, "fuse_raw: null frame %d", k);
-        TRY(h2d(ctx, d, frames[k], N * 4));
-        d_fr[k] = d;
-    }
-    float* d_out; int32_t* d_cnt;
+    const size_t N = (size_t)H * W;
+    const int P = fuse_max_exposures_per_pass();
+    float *d_out, *part = nullptr, *d_kmax = nullptr; int32_t* d_cnt;
     RESERVE(ctx, S_OUT, N * 4, d_out); RESERVE(ctx, S_AUX, N * 4, d_cnt);
-    TRY(pysp_fuse_raw_dev(ctx, d_fr.data(), K, H, W, ev_off, bias, kmax, d_out, d_cnt));
+    if (K > P) { RESERVE(ctx, S_TMP0, N * 4, part); RESERVE(ctx, S_IN2, N * 4, d_kmax); TRY(h2d(ctx, d_kmax, frames[kmax], N * 4)); }
+    ctx->tic();
+    for (int k0 = 0; k0 < K; k0 += P) {                      // the exposures stream through one pass worth of device buffers
+        const int n = K - k0 < P ? K - k0 : P;
+        std::vector<const float*> d_fr((size_t)n);
+        for (int k = 0; k < n; k++) {
+            float* d; RESERVE(ctx, S_FR0 + k, N * 4, d);
+            TRY(h2d(ctx, d, frames[k0 + k], N * 4));        // stream ordered: after the previous pass has read the buffer
+            d_fr[(size_t)k] = d;
+        }
+        const float* km = K > P ? d_kmax : d_fr[(size_t)kmax];
+        LAUNCH_TRY(launch_fuse_raw_pass(ctx->stream, d_fr.data(), n, H, W, ev_off + k0, bias + 4 * k0, k0 == 0, k0 + n == K, km, ev_off[kmax], d_out, d_cnt, part));
+    }
+    ctx->toc();
     TRY(d2h(ctx, out, d_out, N * 4));
     TRY(d2h(ctx, count, d_cnt, N * 4));
     return pysp_ctx_sync(ctx);
@@ -828,24 +850,31 @@ int pysp_fuse_rgb_f32(pysp_ctx* ctx, float* const* frames, int K, size_t npx, co
                       const float* bias, int kmax, const double* M, float* out, int32_t* count, int write_back) {
     CTX_ENTER(ctx);
     if (!frames || !coeff || !applied || !ev_off || !bias || !out || !count) return fail(PYSP_EBADARG, "fuse_rgb: null pointer");
-    if (K < 1 || K > 12 || kmax < 0 || kmax >= K || npx == 0) return fail(PYSP_EBADARG, "fuse_rgb: 1..12 exposures supported (got %d)", K);
-    size_t bytes = npx * 12;
-    std::vector<const float*> d_in(K);
-    std::vector<float*> d_io(K);
-    for (int k = 0; k < K; k++) {
+    if (K < 1 || kmax < 0 || kmax >= K || npx == 0) return fail(PYSP_EBADARG, "fuse_rgb: bad exposure count %d, kmax %d or empty image", K, kmax);
+    for (int k = 0; k < K; k++)
         if (!frames[k]) return fail(PYSP_EBADARG, "fuse_rgb: null frame %d", k);
-        float* d; RESERVE(ctx, S_FR0 + k, bytes, d);
-        TRY(h2d(ctx, d, frames[k], bytes));
-        d_in[k] = d; d_io[k] = d;            // in place: each element is read once before it is written
-    }
-    float* d_out; int32_t* d_cnt;
+    const size_t bytes = npx * 12;
+    const int P = fuse_max_exposures_per_pass();
+    float *d_out, *part = nullptr; int32_t* d_cnt;
     RESERVE(ctx, S_OUT, bytes, d_out); RESERVE(ctx, S_AUX, bytes, d_cnt);
+    if (K > P) RESERVE(ctx, S_TMP0, 2 * bytes, part);
     ctx->tic();
-    LAUNCH_TRY(launch_fuse_rgb(ctx->stream, d_in.data(), write_back ? d_io.data() : nullptr, K, npx, coeff, applied, ev_off, bias, kmax, M, d_out, d_cnt));
+    for (int k0 = 0; k0 < K; k0 += P) {
+        const int n = K - k0 < P ? K - k0 : P;
+        std::vector<const float*> d_in((size_t)n);
+        std::vector<float*> d_io((size_t)n);
+        for (int k = 0; k < n; k++) {
+            float* d; RESERVE(ctx, S_FR0 + k, bytes, d);
+            TRY(h2d(ctx, d, frames[k0 + k], bytes));
+            d_in[(size_t)k] = d; d_io[(size_t)k] = d;       // in place: each element is read once before it is written
+        }
+        LAUNCH_TRY(launch_fuse_rgb_pass(ctx->stream, d_in.data(), write_back ? d_io.data() : nullptr, n, npx, coeff + 3 * k0, applied + k0, ev_off + k0, bias + k0,
+                                        k0 == 0, k0 + n == K, (kmax >= k0 && kmax < k0 + n) ? kmax - k0 : -1, ev_off[kmax], M, d_out, d_cnt, part));
+        if (write_back) for (int k = 0; k < n; k++) TRY(d2h(ctx, frames[k0 + k], d_io[(size_t)k], bytes));      // before the next pass reuses the buffers
+    }
     ctx->toc();
     TRY(d2h(ctx, out, d_out, bytes));
     TRY(d2h(ctx, count, d_cnt, bytes));
-    if (write_back) for (int k = 0; k < K; k++) TRY(d2h(ctx, frames[k], d_io[k], bytes));
     return pysp_ctx_sync(ctx);
 }
 
@@ -853,12 +882,14 @@ int pysp_fuse_rgb_dev(pysp_ctx* ctx, const float* const* d_frames, float* const*
                       const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count) {
     CTX_ENTER(ctx);
     if (!d_frames || !coeff || !applied || !ev_off || !bias || !d_out || !d_count) return fail(PYSP_EBADARG, "fuse_rgb: null pointer");
-    if (K < 1 || K > 12 || kmax < 0 || kmax >= K || npx == 0) return fail(PYSP_EBADARG, "fuse_rgb: 1..12 exposures supported (got %d)", K);
+    if (K < 1 || kmax < 0 || kmax >= K || npx == 0) return fail(PYSP_EBADARG, "fuse_rgb: bad exposure count %d, kmax %d or empty image", K, kmax);
     for (int k = 0; k < K; k++)
         if (!d_frames[k]) return fail(PYSP_EBADARG, "fuse_rgb: null frame %d", k);
+    float* part = nullptr;
+    if (K > fuse_max_exposures_per_pass()) RESERVE(ctx, S_TMP0, npx * 24, part);
     ctx->tic();
     ctx->tl.begin(ctx->stream, "k_fuse_rgb");
-    LAUNCH_TRY(launch_fuse_rgb(ctx->stream, d_frames, d_frames_rt, K, npx, coeff, applied, ev_off, bias, kmax, M, d_out, d_count));
+    LAUNCH_TRY(launch_fuse_rgb(ctx->stream, d_frames, d_frames_rt, K, npx, coeff, applied, ev_off, bias, kmax, M, d_out, d_count, part));
     ctx->tl.end(ctx->stream);
     ctx->toc();
     return PYSP_OK;

@@ -47,8 +47,11 @@ constexpr int NT_A = LQX * LQY / QPT;              // 256: one thread per quad (
 #endif
 
 #ifndef AHD_I16
-#define AHD_I16 1                                 // Lab mode 1: chroma kept as the table's int16 pair in LDS, votes on integers (round 4); 0 = round 3's float planes
+#define AHD_I16 1                                 // build switch for A/B runs: 0 turns the packed layout (template value LAB = 1) back into round 3's float planes
 #endif
+// Template value LAB of k_ahd_select: 0 closed-form Lab (tables in LDS); 1 OpenCV-4.10 LUT path, Lab buffer as packed cells, integer chroma votes (round 4, the
+// default); 2 the same LUT path with round 3's three float planes and float votes (pysp_ctx_set_lab_layout: the form for adversarial colour noise, where
+// every wave of form 1 has to redo its votes in float arithmetic)
 
 constexpr float AH0 = -0x1.053316p-2f, AH1 = 0x1p-1f, AH2 = 0x1.053316p-1f;  // ahd.py:89-94
 
@@ -77,7 +80,7 @@ DEVI void homog_lab(LabTab lt, const uint4* lut, float r, float g, float b, cons
         luma = 0.2126f * sr + 0.7152f * sg + 0.0722f * sb;
         sr = sr / (1.0f + sr); sg = sg / (1.0f + sg); sb = sb / (1.0f + sb);
     }
-    if (LAB == 1) rgb2lab_cv410(lut, sr, sg, sb, L, A, Bq); else rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
+    if (LAB != 0) rgb2lab_cv410(lut, sr, sg, sb, L, A, Bq); else rgb2lab_px(lt, sr, sg, sb, L, A, Bq);
     if (hdr) L = luma;
 }
 
@@ -168,7 +171,7 @@ constexpr int quad_pair_id(int a, int b) {
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     return lo == 0 ? (hi == 1 ? 0 : hi == 2 ? 2 : 4) : lo == 1 ? (hi == 3 ? 3 : 5) : 1;
 }
-template <int DIR, int K0, int K1>
+template <int DIR, int K0, int K1, bool SHARE = true>
 DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4][4], int cnt[4], float pc[6]) {
 #pragma unroll
     for (int k = K0; k < K1; k++) {
@@ -179,10 +182,10 @@ DEVI void vote_quad(const float wl[4][4], const float wa[4][4], const float wq[4
         auto dist = [&](const int y, const int x) -> float {
             const bool quad = y >= 1 && y <= 2 && x >= 1 && x <= 2;
             const int q = quad ? (y - 1) * 2 + (x - 1) : -1;
-            if (quad && q < k) return pc[quad_pair_id(k, q)];
+            if (SHARE && quad && q < k) return pc[quad_pair_id(k, q)];
             const float da = wa[y][x] - ra, db = wq[y][x] - rb;
             const float d = da * da + db * db;
-            if (quad) pc[quad_pair_id(k, q)] = d;
+            if (SHARE && quad) pc[quad_pair_id(k, q)] = d;
             return d;
         };
         // (sharing L(q) - L(p) between the two pixels of a pair the same way -- the negation is a source modifier -- saves another 14 instructions and measures
@@ -314,6 +317,33 @@ DEVI void load_labrows_pk(const float* lab, int lqy, int lqx, bool at_top, bool 
         for (int c = 0; c < 4; c++) {
             if (R0 == 0 && at_top) { wl[0][c] = wl[1][c]; wc[0][c] = wc[1][c]; }
             if (R1 == 4 && at_bot) { wl[3][c] = wl[2][c]; wc[3][c] = wc[2][c]; }      // row 2 already carries its left / right rule
+        }
+    }
+}
+// rows [R0, R1) of the same window as three FLOAT windows for the float vote of round 3 (vote_quad): chroma converted without the 1/64 scale and the -128
+// offset, which cancel in every difference and commute with every rounding (see above)
+template <int R0, int R1>
+DEVI void load_lab_rows_pk_cvt(const float* lab, int lqy, int lqx, bool at_top, bool at_bot, bool at_left, bool at_right, float wl[4][4], float wa[4][4], float wq[4][4]) {
+    const float4* p = reinterpret_cast<const float4*>(lab) + (2 * lqy) * LC4 + lqx;
+#pragma unroll
+    for (int r = R0; r < R1; r++) {
+        const float4 a = p[r * LC4], b = p[r * LC4 + 1];
+        const unsigned c0 = __float_as_uint(a.y), c1 = __float_as_uint(a.w), c2 = __float_as_uint(b.y), c3 = __float_as_uint(b.w);
+        wl[r][0] = a.x; wl[r][1] = a.z; wl[r][2] = b.x; wl[r][3] = b.z;
+        wa[r][0] = (float)(c0 & 0xFFFFu); wa[r][1] = (float)(c1 & 0xFFFFu); wa[r][2] = (float)(c2 & 0xFFFFu); wa[r][3] = (float)(c3 & 0xFFFFu);
+        wq[r][0] = (float)(c0 >> 16); wq[r][1] = (float)(c1 >> 16); wq[r][2] = (float)(c2 >> 16); wq[r][3] = (float)(c3 >> 16);
+        __builtin_amdgcn_sched_barrier(0);          // row by row: the raw cells of all rows must not be in registers together (this path may not cost the kernel its seventh wave)
+    }
+    if (at_top | at_bot | at_left | at_right) {
+#pragma unroll
+        for (int r = R0; r < R1; r++) {
+            if (at_left) { wl[r][0] = wl[r][1]; wa[r][0] = wa[r][1]; wq[r][0] = wq[r][1]; }
+            if (at_right) { wl[r][3] = wl[r][2]; wa[r][3] = wa[r][2]; wq[r][3] = wq[r][2]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (R0 == 0 && at_top) { wl[0][c] = wl[1][c]; wa[0][c] = wa[1][c]; wq[0][c] = wq[1][c]; }
+            if (R1 == 4 && at_bot) { wl[3][c] = wl[2][c]; wa[3][c] = wa[2][c]; wq[3][c] = wq[2][c]; }
         }
     }
 }
@@ -786,6 +816,20 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
 #ifndef AHD_I16_NOGUARD          // (timing experiment only: wrong on hard colour noise)
                 if (big != 0) {          // uniform over the wave; never taken on ordinary content
                     asm volatile("" ::: "memory");                                     // fresh loads: nothing of the integer form stays live into this path
+#ifdef AHD_I16_FAST_FLOAT_FORM          // (A/B only: 78 VGPRs, six waves per SIMD -- the kernel keeps its seventh wave with the frugal form below)
+                    // round 3's float vote (pair sharing, two window pieces) on converted values: the integer form's registers are dead here
+#ifdef AHD_FLOAT_FORM_SHARE
+                    constexpr bool FSHARE = true;
+#else
+                    constexpr bool FSHARE = false;             // (sharing the quad's pair distances costs six registers here: 78 VGPRs, six waves)
+#endif
+                    float wl[4][4], wa[4][4], wq[4][4], pcf[6];
+                    load_lab_rows_pk_cvt<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wa, wq);
+                    if (dir == 0) vote_quad<0, 0, 2, FSHARE>(wl, wa, wq, cnt, pcf); else vote_quad<1, 0, 2, FSHARE>(wl, wa, wq, cnt, pcf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_lab_rows_pk_cvt<3, 4>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wa, wq);
+                    if (dir == 0) vote_quad<0, 2, 4, FSHARE>(wl, wa, wq, cnt, pcf); else vote_quad<1, 2, 4, FSHARE>(wl, wa, wq, cnt, pcf);
+#else
                     float wl[4][4]; unsigned wc[4][4];
                     load_labrows_pk<0, 3>(lab, lqy, lqx, at_top, at_bot, at_left, at_right, wl, wc);
                     unsigned pk = dir == 0 ? vote_quad_pk_f32<0, 0, 2>(wl, wc) : vote_quad_pk_f32<1, 0, 2>(wl, wc);
@@ -794,6 +838,7 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
                     pk |= dir == 0 ? vote_quad_pk_f32<0, 2, 4>(wl, wc) : vote_quad_pk_f32<1, 2, 4>(wl, wc);
 #pragma unroll
                     for (int k = 0; k < 4; k++) cnt[k] = (int)((pk >> (4 * k)) & 15u);
+#endif
                 }
 #endif
             };
@@ -1218,7 +1263,7 @@ __global__ void __launch_bounds__(NT_A, 1) k_ahd_fused(AhdParams a, MedParams m,
 
 // ------------------------------------------------------------------------------------------------
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
-               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl) {
+               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl, int lab_planes) {
     AhdParams a;
     a.labtab = reinterpret_cast<const float4*>(d_labtab);
     a.lablut = reinterpret_cast<const uint4*>(d_lablut);
@@ -1241,7 +1286,8 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
         else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV, LABV, TAILV>), ga, dim3(NT_A), 0, st, a); \
     } while (0)
 #define AHD_LAUNCH(HDRV, LABV) do { if (a.tail != 0) AHD_LAUNCH2(HDRV, LABV, true); else AHD_LAUNCH2(HDRV, LABV, false); } while (0)
-    if (d_lablut) { if (hdr) AHD_LAUNCH(true, 1); else AHD_LAUNCH(false, 1); }
+    if (d_lablut && lab_planes) { if (hdr) AHD_LAUNCH(true, 2); else AHD_LAUNCH(false, 2); }
+    else if (d_lablut) { if (hdr) AHD_LAUNCH(true, 1); else AHD_LAUNCH(false, 1); }
     else { if (hdr) AHD_LAUNCH(true, 0); else AHD_LAUNCH(false, 0); }
 #undef AHD_LAUNCH2
 #undef AHD_LAUNCH

@@ -11,14 +11,21 @@
 // ---- HDR raw fusion -------------------------------------------------------------------------------
 // Pointwise over K exposures: VEC px per thread per frame (float4 when W % 4 == 0, else float2: W is
 // even, so every row start stays 8-byte aligned and column parity is known at compile time).
+// More than MAXK exposures (round 4: the reference takes any number) run as passes of MAXK in order: a pass that is not the last leaves its partial
+// sums in memory -- sum of weights in `part`, weighted sum in `out`, counts in `count` -- and the next one picks them up: the same float32 additions in the
+// same order as one long loop, so the same bits.
 namespace { constexpr int MAXK = 16; }
 struct FuseParams {
     const float* frames[MAXK];
     float ev_off[MAXK];
     float bias[MAXK][4];   // CFA site order r,g1,b,g2
-    int K, kmax, H, W;
+    int K, H, W;
+    int first, last;       // this pass starts from zero / finishes the pixel
+    const float* kmax_frame;   // the exposure with the largest EV offset (raw_hdr.py:143) and its offset: what a pixel without any weight falls back to
+    float kmax_off;
     float* out;
     int32_t* count;
+    float* part;           // (H,W) partial sums of weights between passes (only touched when K > MAXK)
 };
 template <int VEC>
 __global__ void __launch_bounds__(256) k_fuse_raw(FuseParams p) {
@@ -29,8 +36,13 @@ __global__ void __launch_bounds__(256) k_fuse_raw(FuseParams p) {
     size_t o = (size_t)y * p.W + (size_t)VEC * xq;
     float sw[VEC], sp[VEC], v[VEC];
     int cnt[VEC];
+    if (p.first) {
 #pragma unroll
-    for (int t = 0; t < VEC; t++) { sw[t] = 0.0f; sp[t] = 0.0f; cnt[t] = 0; }
+        for (int t = 0; t < VEC; t++) { sw[t] = 0.0f; sp[t] = 0.0f; cnt[t] = 0; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < VEC; t++) { sw[t] = p.part[o + t]; sp[t] = p.out[o + t]; cnt[t] = p.count[o + t]; }
+    }
     for (int k = 0; k < p.K; k++) {
         if (VEC == 4) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(p.frames[k] + o);
         else *reinterpret_cast<float2*>(v) = *reinterpret_cast<const float2*>(p.frames[k] + o);
@@ -43,9 +55,14 @@ __global__ void __launch_bounds__(256) k_fuse_raw(FuseParams p) {
             cnt[t] += wgt > 0.0f ? 1 : 0;                                                   // :141
         }
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(p.frames[p.kmax] + o);
-    else *reinterpret_cast<float2*>(v) = *reinterpret_cast<const float2*>(p.frames[p.kmax] + o);
-    const float mo = p.ev_off[p.kmax];
+    if (!p.last) {
+#pragma unroll
+        for (int t = 0; t < VEC; t++) { p.part[o + t] = sw[t]; p.out[o + t] = sp[t]; p.count[o + t] = cnt[t]; }
+        return;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(p.kmax_frame + o);
+    else *reinterpret_cast<float2*>(v) = *reinterpret_cast<const float2*>(p.kmax_frame + o);
+    const float mo = p.kmax_off;
     float res[VEC];
 #pragma unroll
     for (int t = 0; t < VEC; t++) res[t] = sw[t] == 0.0f ? v[t] * mo : sp[t] / sw[t];       // :144-148
@@ -57,19 +74,22 @@ __global__ void __launch_bounds__(256) k_fuse_raw(FuseParams p) {
         *reinterpret_cast<int2*>(p.count + o) = *reinterpret_cast<int2*>(cnt);
     }
 }
-int launch_fuse_raw(hipStream_t st, const float* const* d_frames, int K, int H, int W, const float* ev_off, const float* bias,
-                    int kmax, float* d_out, int32_t* d_count) {
-    if (K < 1 || K > MAXK || (W & 1)) return -1;
+int fuse_max_exposures_per_pass() { return MAXK; }
+// one pass: n <= MAXK exposures (their offsets and biases), whether it starts / finishes the pixels, and for the finishing pass the largest-offset exposure
+int launch_fuse_raw_pass(hipStream_t st, const float* const* d_frames, int n, int H, int W, const float* ev_off, const float* bias, int first, int last,
+                         const float* d_kmax_frame, float kmax_off, float* d_out, int32_t* d_count, float* d_part) {
+    if (n < 1 || n > MAXK || (W & 1) || (!(first && last) && !d_part) || (last && !d_kmax_frame)) return -1;
+    uintptr_t align = reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_count) | reinterpret_cast<uintptr_t>(d_kmax_frame);
     FuseParams p;
-    uintptr_t align = reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_count);
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < n; k++) {
         p.frames[k] = d_frames[k];
         p.ev_off[k] = ev_off[k];
         for (int c = 0; c < 4; c++) p.bias[k][c] = bias[k * 4 + c];
         align |= reinterpret_cast<uintptr_t>(d_frames[k]);
     }
     if (align & 15) return -1;
-    p.K = K; p.kmax = kmax; p.H = H; p.W = W; p.out = d_out; p.count = d_count;
+    p.K = n; p.H = H; p.W = W; p.out = d_out; p.count = d_count; p.part = d_part;
+    p.first = first; p.last = last; p.kmax_frame = d_kmax_frame; p.kmax_off = kmax_off;
     if ((W & 3) == 0) {
         dim3 g((W / 4 + 255) / 256, H);
         hipLaunchKernelGGL(k_fuse_raw<4>, g, dim3(256), 0, st, p);
@@ -79,27 +99,43 @@ int launch_fuse_raw(hipStream_t st, const float* const* d_frames, int K, int H, 
     }
     return CHECK_LAUNCH();
 }
+int launch_fuse_raw(hipStream_t st, const float* const* d_frames, int K, int H, int W, const float* ev_off, const float* bias,
+                    int kmax, float* d_out, int32_t* d_count, float* d_part) {
+    if (K < 1 || kmax < 0 || kmax >= K || (K > MAXK && !d_part)) return -1;
+    for (int k0 = 0; k0 < K; k0 += MAXK) {
+        const int n = K - k0 < MAXK ? K - k0 : MAXK;
+        int rc = launch_fuse_raw_pass(st, d_frames + k0, n, H, W, ev_off + k0, bias + 4 * k0, k0 == 0, k0 + n == K, d_frames[kmax], ev_off[kmax], d_out, d_count, d_part);
+        if (rc) return rc;
+    }
+    return 0;
+}
 
-// ---- fusion of debayered exposures (raw_hdr.py:7-83) --------------------------------------------------
-// One thread per RGB pixel; see oracle orc_fuse_rgb for the op order.  Optionally applies the CCM
-// (cam_to_lin_srgb, clip off) and writes back the undo/apply round-tripped images.
+// (more than MAXK exposures: passes as in the raw fusion; between passes the weight sums live in part[0 .. 3 npx), the weighted sums in `out`, the counts in
+// `count` and the largest-offset exposure's white-balanced pixel in part[3 npx .. 6 npx))
 struct FuseRgbParams {
     const float* frames[MAXK];
     float* frames_out[MAXK];
     float coeff[MAXK][3];
     float ev_off[MAXK], bias[MAXK];
     int applied[MAXK];
-    int K, kmax, use_ccm;
+    int K, kmax, use_ccm;      // kmax: index inside THIS pass of the exposure with the largest offset, or -1
+    int first, last;
+    float kmax_off;
     size_t npx;
     Ccm ccm;
     float* out;
     int32_t* count;
+    float* part;
 };
 __global__ void __launch_bounds__(256) k_fuse_rgb(FuseRgbParams p) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.npx) return;
     float sw[3] = {0, 0, 0}, sp[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};
     int cnt[3] = {0, 0, 0};
+    if (!p.first) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { sw[c] = p.part[3 * i + c]; vmax[c] = p.part[3 * p.npx + 3 * i + c]; sp[c] = p.out[3 * i + c]; cnt[c] = p.count[3 * i + c]; }
+    }
     for (int k = 0; k < p.K; k++) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -114,10 +150,15 @@ __global__ void __launch_bounds__(256) k_fuse_rgb(FuseRgbParams p) {
             if (p.frames_out[k]) p.frames_out[k][3 * i + c] = v;
         }
     }
+    if (!p.last) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { p.part[3 * i + c] = sw[c]; p.part[3 * p.npx + 3 * i + c] = vmax[c]; p.out[3 * i + c] = sp[c]; p.count[3 * i + c] = cnt[c]; }
+        return;
+    }
     float res[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        res[c] = sw[c] == 0.0f ? vmax[c] * p.ev_off[p.kmax] : sp[c] / sw[c];
+        res[c] = sw[c] == 0.0f ? vmax[c] * p.kmax_off : sp[c] / sw[c];
         p.count[3 * i + c] = cnt[c];
     }
     if (p.use_ccm) {
@@ -128,20 +169,34 @@ __global__ void __launch_bounds__(256) k_fuse_rgb(FuseRgbParams p) {
         p.out[3 * i] = res[0]; p.out[3 * i + 1] = res[1]; p.out[3 * i + 2] = res[2];
     }
 }
-int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int K, size_t npx, const float* coeff,
-                    const int* applied, const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count) {
-    if (K < 1 || K > MAXK || kmax < 0 || kmax >= K) return -1;
+// one pass of the RGB fusion: n <= MAXK exposures; kmax_local = index inside the pass of the largest-offset exposure, or -1 when it is in another pass
+int launch_fuse_rgb_pass(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int n, size_t npx, const float* coeff, const int* applied,
+                         const float* ev_off, const float* bias, int first, int last, int kmax_local, float kmax_off, const double* M, float* d_out,
+                         int32_t* d_count, float* d_part) {
+    if (n < 1 || n > MAXK || kmax_local >= n || (!(first && last) && !d_part)) return -1;
     FuseRgbParams p;
-    for (int k = 0; k < K; k++) {
+    for (int k = 0; k < n; k++) {
         p.frames[k] = d_frames[k];
         p.frames_out[k] = d_frames_out ? d_frames_out[k] : nullptr;
         for (int c = 0; c < 3; c++) p.coeff[k][c] = coeff[k * 3 + c];
         p.ev_off[k] = ev_off[k]; p.bias[k] = bias[k]; p.applied[k] = applied[k];
     }
-    p.K = K; p.kmax = kmax; p.npx = npx; p.out = d_out; p.count = d_count; p.use_ccm = M != nullptr;
+    p.K = n; p.kmax = kmax_local; p.kmax_off = kmax_off; p.first = first; p.last = last;
+    p.npx = npx; p.out = d_out; p.count = d_count; p.part = d_part; p.use_ccm = M != nullptr;
     for (int i = 0; i < 9; i++) p.ccm.m[i] = M ? M[i] : 0.0;
     hipLaunchKernelGGL(k_fuse_rgb, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, p);
     return CHECK_LAUNCH();
+}
+int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int K, size_t npx, const float* coeff,
+                    const int* applied, const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count, float* d_part) {
+    if (K < 1 || kmax < 0 || kmax >= K || (K > MAXK && !d_part)) return -1;
+    for (int k0 = 0; k0 < K; k0 += MAXK) {
+        const int n = K - k0 < MAXK ? K - k0 : MAXK;
+        int rc = launch_fuse_rgb_pass(st, d_frames + k0, d_frames_out ? d_frames_out + k0 : nullptr, n, npx, coeff + 3 * k0, applied + k0, ev_off + k0, bias + k0,
+                                      k0 == 0, k0 + n == K, (kmax >= k0 && kmax < k0 + n) ? kmax - k0 : -1, ev_off[kmax], M, d_out, d_count, d_part);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ---- WarpRectilinear ------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ int launch_colour_tail(hipStream_t st, const float* in, size_t npx, const double
 // d_tmp0/d_tmp1 are (H,W,3) scratch images (only needed when stages >= 1 / >= 2).
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut /* Lab mode 1, else NULL */,
-               Timeline* tl = nullptr);
+               Timeline* tl = nullptr, int lab_planes = 0 /* Lab mode 1: float Lab planes and float votes (round 3's form) instead of packed cells */);
 
 // A batch of n frames through AHD with one median stage (Lab mode 1): n + 1 launches, select tiles of frame i + 1 and median tiles of frame i sharing one grid
 // (role-interleaved kernel, k_ahd.hip).  ahd_pipelined_ok says whether the batch qualifies; the caller falls back to n calls of launch_ahd otherwise.
@@ -54,10 +54,18 @@ int launch_highpass(hipStream_t st, const float* g, int H, int W, float* out);
 int launch_resample_channel(hipStream_t st, const float* sub, const float* g_sub, const float* g_hf, int h, int w, int pos, float* out);
 
 // k_misc.hip
+// Any number of exposures: more than fuse_max_exposures_per_pass() run as passes in order, with partial sums carried in d_part -- (H,W) floats for the raw
+// fusion, 6 npx floats for the RGB one (may be NULL when K fits one pass).  Same additions in the same order: same bits as one pass.
+int fuse_max_exposures_per_pass();
+int launch_fuse_raw_pass(hipStream_t st, const float* const* d_frames, int n, int H, int W, const float* ev_off, const float* bias, int first, int last,
+                         const float* d_kmax_frame, float kmax_off, float* d_out, int32_t* d_count, float* d_part);
+int launch_fuse_rgb_pass(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int n, size_t npx, const float* coeff, const int* applied,
+                         const float* ev_off, const float* bias, int first, int last, int kmax_local, float kmax_off, const double* M, float* d_out,
+                         int32_t* d_count, float* d_part);
 int launch_fuse_raw(hipStream_t st, const float* const* d_frames_host_array, int K, int H, int W, const float* ev_off,
-                    const float* bias, int kmax, float* d_out, int32_t* d_count);
+                    const float* bias, int kmax, float* d_out, int32_t* d_count, float* d_part = nullptr);
 int launch_fuse_rgb(hipStream_t st, const float* const* d_frames, float* const* d_frames_out, int K, size_t npx, const float* coeff,
-                    const int* applied, const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count);
+                    const int* applied, const float* ev_off, const float* bias, int kmax, const double* M, float* d_out, int32_t* d_count, float* d_part = nullptr);
 int launch_warp_table(hipStream_t st, float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
                       float cxn, float cyn, float scale, const float* d_seed, float* d_table);
 int launch_warp_remap(hipStream_t st, const float* d_in, float* d_out, int H, int W, const double* coeffs, int planes, double cxn,

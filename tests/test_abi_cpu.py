@@ -196,11 +196,13 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
     bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     hot = {k: v for k, v in kernels.items() if "k_ahd_select" in k or "k_ahd_median_stage" in k}
-    assert len(hot) == 33                                            # 32 select variants (tiny / uint16 / HDR metric / Lab restatement / colour tail) and the median stage
+    assert len(hot) == 49                                            # 48 select variants (tiny / uint16 / HDR metric / Lab form 0, 1, 2 / colour tail) and the median stage
     for k, v in hot.items():
         if "k_ahd_median_stage" in k:                                # five 256-thread workgroups per CU: <= 96 VGPRs and <= 32 KB of LDS
             assert v["vgpr_count"] <= 96 and v["group_segment_fixed_size"] <= 32768, (k, v)
-        elif "Li1E" in k:                                            # Lab mode 1 (default): SIX workgroups per CU: <= 80 VGPRs, <= 163840 / 6 bytes of LDS
+        elif "Li1E" in k:                                            # Lab mode 1, packed cells (round 4, the default): SEVEN workgroups per CU: <= 72 VGPRs, <= 163840 / 7 bytes of LDS
+            assert v["vgpr_count"] <= 72 and v["group_segment_fixed_size"] <= 163840 // 7, (k, v)
+        elif "Li2E" in k:                                            # Lab mode 1, float planes (round 3's form): SIX workgroups per CU: <= 80 VGPRs, <= 163840 / 6 bytes of LDS
             assert v["vgpr_count"] <= 80 and v["group_segment_fixed_size"] <= 163840 // 6, (k, v)
         else:                                                        # Lab mode 0 carries 12 KB of tables in LDS: four workgroups per CU
             assert v["vgpr_count"] <= 96 and v["group_segment_fixed_size"] <= 163840 // 4, (k, v)

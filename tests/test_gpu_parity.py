@@ -657,17 +657,20 @@ def test_standalone_eag_helpers(orc):
 
 
 def test_fuse_raw_sixteen_exposures(orc, wbobj):
-    """Upper limit of the ABI: 16 exposures through the host entry point."""
+    """One pass worth of exposures (16) through the host entry point -- and, since round 4, more: the reference's loops take any number of exposures, the
+    library runs them as passes of 16 with the partial sums carried between passes (same additions in the same order: same bits)."""
     from pysp_amd.raw_hdr import fuse_exposures_to_raw
     rng = np.random.default_rng(4)
-    K, H, W = 16, 20, 36
-    frames = [rng.random((H, W), dtype=np.float32) for _ in range(K)]
-    evs = [8.0 + 0.25 * k for k in range(K)]
-    hdr, cnt = fuse_exposures_to_raw([_raw(f, wbobj, ev=e) for f, e in zip(frames, evs)])
-    ref, refc, _, _ = orc.fuse_raw(frames, evs, 1.0 / MULT)
-    assert np.array_equal(hdr.sensor_scaled, ref) and np.array_equal(cnt, refc)
-    with pytest.raises(ValueError):
-        fuse_exposures_to_raw([_raw(frames[0], wbobj, ev=9.0)] * 17)
+    H, W = 20, 36
+    for K in (16, 17, 37):
+        frames = [rng.random((H, W), dtype=np.float32) for _ in range(K)]
+        frames[K // 2][3:9, 5:11] = 0.0                       # some pixels carry no weight in one exposure
+        for f in frames:
+            f[12:14, 20:24] = 1.0                             # ... and some in none: the fallback to the largest-offset exposure (raw_hdr.py:144-148)
+        evs = [8.0 + 0.25 * ((k * 7) % K) for k in range(K)]      # the largest offset sits in the middle of the list, not in the last pass
+        hdr, cnt = fuse_exposures_to_raw([_raw(f, wbobj, ev=e) for f, e in zip(frames, evs)])
+        ref, refc, _, _ = orc.fuse_raw(frames, evs, 1.0 / MULT)
+        assert np.array_equal(hdr.sensor_scaled, ref) and np.array_equal(cnt, refc), K
 
 
 def test_warp_with_prior_and_generic_remap(orc):

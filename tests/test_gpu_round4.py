@@ -194,3 +194,105 @@ print("RCCL_WORLD1_OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0 and "RCCL_WORLD1_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_config1_draft_12mp_full_size(orc):
+    """BASELINE configs[0] at its own size (VERDICT r3 Weak 7: the 4000 x 3000 Draft frame was never compared with anything at full size): QualityDemosaic.Draft
+    + to_lin_srgb through the drop-in classes on the whole 12 MP synthetic frame, bit for bit against the oracle."""
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.synth import default_wb, rggb_frame
+    wb, M = _wbM(orc)
+    H, W = 3000, 4000
+    bay = rggb_frame(H, W, 1000)
+    dem = RawRggbBayerData(bay, default_wb(), 10.0, 1.0).demosaic(QualityDemosaic.Draft)
+    lin = np.asarray(dem.to_lin_srgb())
+    raw = orc.demosaic_draft(bay, wb)
+    assert lin.shape == (H, W, 3) and np.array_equal(lin, orc.cam_to_rgb(raw, M, True))
+    assert np.array_equal(np.asarray(dem.image), raw)
+
+
+def test_fusions_take_any_number_of_exposures(orc):
+    """VERDICT r3 Weak 9: the reference's fusion loops take any number of exposures; until round 3 the library stopped at 16 (raw) / 12 (RGB).  Now more than one
+    pass worth of them run as passes of 16 in order with the partial sums carried in a workspace block.  Device and host entry points, raw and RGB, 35 and 20
+    exposures, the largest-offset exposure in a middle pass, pixels without any weight, the wb_undo / wb_apply write-back: bit for bit against the oracle."""
+    import ctypes
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    wb, M = _wbM(orc)
+    rng = np.random.default_rng(99)
+    pipe = DevicePipeline(0)
+    # raw, device resident
+    H, W, K = 48, 68, 35
+    frames = [np.clip(rng.random((H, W), dtype=np.float32) * np.float32(1.3), 0, 1) for _ in range(K)]
+    for f in frames:
+        f[7:9, 10:14] = 1.0
+    evs = [9.0 + 0.1 * ((k * 11) % K) for k in range(K)]
+    fused, count, _, _ = pipe.fuse_raw([torch.from_numpy(f).cuda() for f in frames], evs, wb)
+    rf, rc = orc.fuse_raw(frames, evs, wb)[:2]
+    assert np.array_equal(fused.cpu().numpy(), rf) and np.array_equal(count.cpu().numpy(), rc)
+    # RGB, host entry point with write-back, and device entry point
+    K, shape = 20, (24, 40, 3)
+    imgs = [rng.random(shape, dtype=np.float32) for _ in range(K)]
+    for a in imgs:
+        a[5:7, 8:12] = 0.0
+    coeffs = np.stack([(1.0 / rng.uniform(0.4, 1.0, 3)).astype(np.float32) for _ in range(K)])
+    applied = np.array([k % 3 != 0 for k in range(K)], np.int32)
+    evs = [10.0 + 0.2 * ((k * 7) % K) for k in range(K)]
+    ref_out, ref_cnt, ref_imgs = orc.fuse_rgb(imgs, evs, coeffs, M, applied)
+    tgt = sum(evs) / K
+    offs = [2 ** (e - tgt) for e in evs]
+    bias = np.array([1.6 ** (-0.1 * o) for o in offs]).astype(np.float32)
+    off32 = np.array(offs, np.float32)
+    kmax = max(k for k, o in enumerate(offs) if o == max(offs))
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)
+    L, ctx = _lib.lib(), _lib.default_context()
+    npx = shape[0] * shape[1]
+    host = [a.copy() for a in imgs]
+    out = np.empty(shape, np.float32); cnt = np.empty(shape, np.int32)
+    cf = np.ascontiguousarray(coeffs.reshape(-1))
+    _lib.check(L.pysp_fuse_rgb_f32(ctx.handle, (ctypes.c_void_p * K)(*[h.ctypes.data for h in host]), K, ctypes.c_size_t(npx), cf.ctypes.data_as(fp),
+                                   applied.ctypes.data_as(ip), off32.ctypes.data_as(fp), bias.ctypes.data_as(fp), kmax, _lib.mat9(M), _lib.ptr(out), _lib.ptr(cnt), 1))
+    assert np.array_equal(out, ref_out) and np.array_equal(cnt, ref_cnt) and all(np.array_equal(h, r) for h, r in zip(host, ref_imgs))
+    d_in = [torch.from_numpy(a).cuda() for a in imgs]
+    d_rt = [torch.empty_like(t) for t in d_in]
+    d_out = torch.empty(shape, dtype=torch.float32, device="cuda"); d_cnt = torch.empty(shape, dtype=torch.int32, device="cuda")
+    pipe._enter()
+    _lib.check(L.pysp_fuse_rgb_dev(pipe.ctx.handle, (ctypes.c_void_p * K)(*[t.data_ptr() for t in d_in]), (ctypes.c_void_p * K)(*[t.data_ptr() for t in d_rt]), K,
+                                   ctypes.c_size_t(npx), cf.ctypes.data_as(fp), applied.ctypes.data_as(ip), off32.ctypes.data_as(fp), bias.ctypes.data_as(fp), kmax,
+                                   _lib.mat9(M), ctypes.c_void_p(d_out.data_ptr()), ctypes.c_void_p(d_cnt.data_ptr())))
+    pipe.sync()
+    assert np.array_equal(d_out.cpu().numpy(), ref_out) and np.array_equal(d_cnt.cpu().numpy(), ref_cnt)
+    assert all(np.array_equal(t.cpu().numpy(), r) for t, r in zip(d_rt, ref_imgs))
+
+
+def test_lab_layouts_agree_on_any_content(orc):
+    """pysp_ctx_set_lab_layout: packed cells with integer chroma votes (default) and float planes with float votes are two forms of the same arithmetic.  Both
+    equal the oracle bit for bit on the benchmark scene (no wave leaves the integer form), on pure noise (every wave redoes its votes in float32) and on a frame
+    whose left half is scene and right half noise (both kinds of wave in one launch); HDR metric on and off; the switch is per context and reversible."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import random_frame, rggb_frame
+    wb, M = _wbM(orc)
+    pipe = DevicePipeline(0)
+    assert pipe.ctx.get_lab_layout() == 0
+    H, W = 180, 260
+    mixed = rggb_frame(H, W, 1000).copy()
+    mixed[:, W // 2:] = random_frame(H, W, 8)[:, W // 2:]
+    frames = [rggb_frame(H, W, 1000), random_frame(H, W, 8), mixed]
+    try:
+        for hdr in (False, True):
+            refs = [orc.demosaic_ahd(f * (np.float32(3.0) if hdr else np.float32(1.0)), wb, M, hdr, 1) for f in frames]
+            for layout in ("planes", "packed"):
+                pipe.ctx.set_lab_layout(layout)
+                assert pipe.ctx.get_lab_layout() == (1 if layout == "planes" else 0)
+                for f, r in zip(frames, refs):
+                    d = torch.from_numpy(f).cuda()
+                    got = pipe.demosaic(d * 3.0 if hdr else d, wb, M, _lib.QUALITY_BEST, hdr, 1).cpu().numpy()
+                    assert np.array_equal(got, r, equal_nan=True), (hdr, layout)
+        with pytest.raises(ValueError):
+            pipe.ctx.set_lab_layout(2)
+    finally:
+        pipe.ctx.set_lab_layout(0)
