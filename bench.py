@@ -83,9 +83,10 @@ def parse_args(argv=None):
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo rehearses the N > 1 path with host-staged collectives, ranks may share a GPU)")
     ap.add_argument("--lab-mode", default="cv410_lut", choices=["closed_form", "cv410_lut"],
                     help="restatement of cv2.cvtColor(RGB2LAB) behind AHD's homogeneity vote (pysp_ctx_set_lab_mode)")
-    ap.add_argument("--lab-layout", default="packed", choices=["packed", "planes"],
-                    help="Lab mode 1 inside the AHD select kernel (same results): packed cells + integer chroma votes (default, fastest on ordinary content) or "
-                         "float planes + float votes (round 3's form: content-independent speed)")
+    ap.add_argument("--lab-layout", default="auto", choices=["auto", "packed", "planes"],
+                    help="Lab mode 1 inside the AHD select kernel (same results): packed cells + integer chroma votes (fastest on ordinary content), float planes + "
+                         "float votes (round 3's form: content-independent speed), or auto (default: packed, switching to planes while the content keeps sending "
+                         "waves through the float form of the vote)")
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (under a launcher): exercises the RCCL broadcast / all_reduce / barrier code path on one GPU")

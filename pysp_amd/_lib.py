@@ -42,6 +42,7 @@ _SIGNATURES = {
     "pysp_ctx_set_lab_lut": (_int, [_vp, _vp]),
     "pysp_ctx_set_lab_layout": (_int, [_vp, _int]),
     "pysp_ctx_get_lab_layout": (_int, [_vp]),
+    "pysp_ctx_lab_layout_in_use": (_int, [_vp]),
     "pysp_ctx_get_lab_lut": (_int, [_vp, _vp]),
     "pysp_ctx_set_stream": (_int, [_vp, _vp]),
     "pysp_ctx_get_stream": (_vp, [_vp]),
@@ -176,8 +177,8 @@ class Context:
         self.device = int(device)
         if os.environ.get("PYSP_LAB_MODE", "") in ("0", "closed_form"):      # default is 1, the OpenCV 4.10 LUT path
             self.set_lab_mode(0)
-        if os.environ.get("PYSP_LAB_LAYOUT", "") in ("1", "planes"):
-            self.set_lab_layout(1)
+        if os.environ.get("PYSP_LAB_LAYOUT", "") in ("0", "1", "packed", "planes"):
+            self.set_lab_layout({"0": 0, "1": 1}.get(os.environ["PYSP_LAB_LAYOUT"], os.environ["PYSP_LAB_LAYOUT"]))
 
     @property
     def handle(self):
@@ -195,13 +196,18 @@ class Context:
         return int(lib().pysp_ctx_get_lab_mode(self.handle))
 
     def set_lab_layout(self, layout) -> None:
-        """Lab mode 1 inside the AHD select kernel: 0 / "packed" (default: integer chroma votes, fastest on ordinary content) or 1 / "planes" (float votes:
-        the same speed on any content, e.g. synthetic colour noise).  Same results either way."""
-        layout = {"packed": 0, "planes": 1}.get(layout, layout)
+        """Lab mode 1 inside the AHD select kernel: -1 / "auto" (default: packed, switching to planes while the content keeps sending waves through the float
+        form of the vote), 0 / "packed" (integer chroma votes, fastest on ordinary content) or 1 / "planes" (float votes: the same speed on any content, e.g.
+        synthetic colour noise).  Same results either way."""
+        layout = {"auto": -1, "packed": 0, "planes": 1}.get(layout, layout)
         check(lib().pysp_ctx_set_lab_layout(self.handle, int(layout)))
 
     def get_lab_layout(self) -> int:
         return int(lib().pysp_ctx_get_lab_layout(self.handle))
+
+    def lab_layout_in_use(self) -> int:
+        """0 (packed) or 1 (planes): what the next AHD call launches."""
+        return int(lib().pysp_ctx_lab_layout_in_use(self.handle))
 
     def set_lab_lut(self, grid=None) -> None:
         """The 33^3 grid of lab mode 1 as data: a (33,33,33,3) int16 array ([B][G][R] node, (L, a, b) scaled as OpenCV's RGB2LabLUT_s16) recorded

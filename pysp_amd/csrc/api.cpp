@@ -64,7 +64,25 @@ struct pysp_ctx {
     float* labtab = nullptr;     // LAB_SLOTS x float4 in the device layout of lab_tables.h
     int lab_mode = 1;            // 1 (default): OpenCV 4.10's LUT + trilinear restatement; 0: closed-form Lab (tables above)
     void* lablut = nullptr;      // mode 1: [34][34][34] x 64 B grid (devmath.h)
-    int lab_layout = 0;          // mode 1: 0 packed Lab cells + integer chroma votes (default), 1 float planes + float votes (pysp_ctx_set_lab_layout)
+    // Lab mode 1 inside the AHD select kernel (pysp_ctx_set_lab_layout): -1 automatic (default), 0 packed Lab cells + integer chroma votes, 1 float planes + float
+    // votes.  Same bits either way.  The packed form is 2-3 % faster unless the content makes its waves redo their votes in float arithmetic (neighbouring pixels
+    // 64 Lab units of chroma apart: synthetic colour noise), where it is 16 % slower.  Automatic: the packed kernel keeps two cumulative device counters (tiles in
+    // which that happened, tiles launched); every LAYOUT_SAMPLE-th packed launch ONE 8-byte copy to page-locked memory is enqueued behind the kernels (nobody
+    // waits for it).  States: PACKED -- a new sample in which more than a quarter of the tiles took the float form starts a HOLD of `layout_hold_len` planes
+    // launches; then a PROBE of exactly LAYOUT_SAMPLE packed launches with a sample behind them; then WAIT -- planes launches until that sample has landed
+    // (a caller that enqueues hundreds of frames ahead of the GPU sees it late: first version, profiles/r4_ab_lab_layouts_auto_v1_host_runs_ahead.log) -- and
+    // back to PACKED if it was clean, or to a HOLD twice as long (at most 4096) if not.
+    int lab_layout = -1;
+    enum { L_PACKED = 0, L_HOLD = 1, L_PROBE = 2, L_WAIT = 3 };
+    int layout_state = L_PACKED;
+    int layout_now = 0;                  // what the next automatic launch uses: 0 packed, 1 planes
+    unsigned* d_layout_count = nullptr;  // device: { float-form tiles, tiles launched }, cumulative
+    volatile unsigned long long* h_layout_count = nullptr;   // page-locked copy of the pair as of the last finished sample
+    unsigned long long layout_last = 0;  // the last sample acted upon
+    unsigned layout_launches = 0, layout_left = 0, layout_hold_len = 256;
+    unsigned layout_tiles_enqueued = 0;  // host-side twin of the device's `tiles launched` (cumulative, wraps like it)
+    unsigned layout_probe_target = 0;    // value of that count when the probe's sample was enqueued
+    static constexpr unsigned LAYOUT_SAMPLE = 16, LAYOUT_HOLD = 256, LAYOUT_HOLD_MAX = 4096;
     std::vector<int16_t> lab_grid;   // the 33^3 x 3 grid the device copy was built from (built-in restatement, or injected: pysp_ctx_set_lab_lut)
     Timeline tl;
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
@@ -243,6 +261,13 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
         if (hipMalloc(&c->lablut, dev.size() * sizeof(int16_t)) != hipSuccess ||
             hipMemcpy(c->lablut, dev.data(), dev.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) { fail(PYSP_ENOMEM, "Lab grid upload failed"); pysp_ctx_destroy(c); return nullptr; }
     }
+    {
+        void* h = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_layout_count), 16) != hipSuccess || hipMemset(c->d_layout_count, 0, 16) != hipSuccess ||
+            hipHostMalloc(&h, 16, hipHostMallocDefault) != hipSuccess) { fail(PYSP_ENOMEM, "layout counter allocation failed"); pysp_ctx_destroy(c); return nullptr; }
+        c->h_layout_count = static_cast<volatile unsigned long long*>(h);
+        c->h_layout_count[0] = 0; c->h_layout_count[1] = 0;
+    }
     return c;
 }
 
@@ -258,6 +283,8 @@ void pysp_ctx_destroy(pysp_ctx* c) {
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
     if (c->labtab) { e = hipFree(c->labtab); (void)e; }
     if (c->lablut) { e = hipFree(c->lablut); (void)e; }
+    if (c->d_layout_count) { e = hipFree(c->d_layout_count); (void)e; }
+    if (c->h_layout_count) { e = hipHostFree(const_cast<unsigned long long*>(c->h_layout_count)); (void)e; }
     for (int i = 0; i < 2 * Timeline::MAXK; i++) if (c->tl.ev[i]) { e = hipEventDestroy(c->tl.ev[i]); (void)e; }
     if (c->ev0) { e = hipEventDestroy(c->ev0); (void)e; }
     if (c->ev1) { e = hipEventDestroy(c->ev1); (void)e; }
@@ -280,11 +307,15 @@ int pysp_ctx_set_lab_mode(pysp_ctx* ctx, int mode) {
 int pysp_ctx_get_lab_mode(pysp_ctx* ctx) { return ctx ? ctx->lab_mode : -1; }
 int pysp_ctx_set_lab_layout(pysp_ctx* ctx, int layout) {
     CTX_ENTER(ctx);
-    if (layout != 0 && layout != 1) return fail(PYSP_EBADARG, "lab layout must be 0 (packed cells, integer chroma votes) or 1 (float planes, float votes)");
+    if (layout < -1 || layout > 1) return fail(PYSP_EBADARG, "lab layout must be -1 (automatic), 0 (packed cells, integer chroma votes) or 1 (float planes, float votes)");
     ctx->lab_layout = layout;
+    ctx->layout_now = layout == 1 ? 1 : 0;
+    ctx->layout_state = pysp_ctx::L_PACKED; ctx->layout_left = 0; ctx->layout_hold_len = pysp_ctx::LAYOUT_HOLD;
+    ctx->layout_last = ctx->h_layout_count ? ctx->h_layout_count[0] : 0;
     return PYSP_OK;
 }
-int pysp_ctx_get_lab_layout(pysp_ctx* ctx) { return ctx ? ctx->lab_layout : -1; }
+int pysp_ctx_get_lab_layout(pysp_ctx* ctx) { return ctx ? ctx->lab_layout : -2; }
+int pysp_ctx_lab_layout_in_use(pysp_ctx* ctx) { return ctx ? (ctx->lab_layout == -1 ? ctx->layout_now : ctx->lab_layout) : -2; }
 
 int pysp_ctx_set_lab_lut(pysp_ctx* ctx, const int16_t* grid) {
     CTX_ENTER(ctx);
@@ -585,7 +616,54 @@ static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, c
         size_t bytes = (size_t)H * W * 12;
         if (stages >= 1) RESERVE(ctx, S_TMP0, bytes, t0);
         if (stages >= 2) RESERVE(ctx, S_TMP1, bytes, t1);
-        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl, ctx->lab_layout));
+        int planes = ctx->lab_layout == 1;
+        unsigned* counter = nullptr;
+        if (ctx->lab_mode == 1 && ctx->lab_layout == -1) {           // automatic layout: the state machine described at pysp_ctx::lab_layout
+            const unsigned long long v = ctx->h_layout_count[0];       // one aligned 8-byte word: { float-form tiles, tiles launched } of the last finished sample
+            if (v != ctx->layout_last && (ctx->layout_state == pysp_ctx::L_PACKED || ctx->layout_state == pysp_ctx::L_WAIT)) {
+                // PACKED: the launches since the last sample acted upon; WAIT: exactly the probe's launches (the counters as they stood when the probe began were
+                // copied to the second page-locked word, in stream order before this sample)
+                const unsigned long long base = ctx->layout_state == pysp_ctx::L_WAIT ? ctx->h_layout_count[1] : ctx->layout_last;
+                const unsigned d_ff = (unsigned)(v & 0xffffffffull) - (unsigned)(base & 0xffffffffull);      // (cumulative counters: differences survive a wrap)
+                const unsigned d_tiles = (unsigned)(v >> 32) - (unsigned)(base >> 32);
+                const bool noisy = d_tiles > 0 && (unsigned long long)d_ff * 4ull > d_tiles;
+                const bool probe_back = (int)((unsigned)(v >> 32) - ctx->layout_probe_target) >= 0;      // this sample covers the probe's launches
+                if (ctx->layout_state == pysp_ctx::L_PACKED) {
+                    ctx->layout_last = v;
+                    if (noisy) { ctx->layout_state = pysp_ctx::L_HOLD; ctx->layout_left = ctx->layout_hold_len; }
+                } else if (probe_back) {
+                    ctx->layout_last = v;
+                    if (noisy) {
+                        ctx->layout_hold_len = ctx->layout_hold_len * 2 > pysp_ctx::LAYOUT_HOLD_MAX ? pysp_ctx::LAYOUT_HOLD_MAX : ctx->layout_hold_len * 2;
+                        ctx->layout_state = pysp_ctx::L_HOLD; ctx->layout_left = ctx->layout_hold_len;
+                    } else {
+                        ctx->layout_hold_len = pysp_ctx::LAYOUT_HOLD; ctx->layout_state = pysp_ctx::L_PACKED;
+                    }
+                }
+            }
+            if (ctx->layout_state == pysp_ctx::L_HOLD && ctx->layout_left == 0) {
+                ctx->layout_state = pysp_ctx::L_PROBE; ctx->layout_left = pysp_ctx::LAYOUT_SAMPLE;
+                HIP_TRY(hipMemcpyAsync(const_cast<unsigned long long*>(ctx->h_layout_count) + 1, ctx->d_layout_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // the probe's baseline
+            }
+            planes = ctx->layout_state == pysp_ctx::L_HOLD || ctx->layout_state == pysp_ctx::L_WAIT;
+            if (!planes) counter = ctx->d_layout_count;
+        }
+        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl, planes, counter));
+        if (ctx->lab_mode == 1 && ctx->lab_layout == -1) {
+            bool sample = false;
+            if (counter) {
+                ctx->layout_tiles_enqueued += (unsigned)ahd_select_tiles(H, W);
+                if (ctx->layout_state == pysp_ctx::L_PROBE) {
+                    if (--ctx->layout_left == 0) { sample = true; ctx->layout_probe_target = ctx->layout_tiles_enqueued; ctx->layout_state = pysp_ctx::L_WAIT; }
+                } else if (++ctx->layout_launches % pysp_ctx::LAYOUT_SAMPLE == 0) {
+                    sample = true;
+                }
+            } else if (ctx->layout_state == pysp_ctx::L_HOLD) {
+                ctx->layout_left--;
+            }
+            if (sample) HIP_TRY(hipMemcpyAsync(const_cast<unsigned long long*>(ctx->h_layout_count), ctx->d_layout_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->layout_now = (ctx->layout_state == pysp_ctx::L_HOLD && ctx->layout_left > 0) || ctx->layout_state == pysp_ctx::L_WAIT;
+        }
     } else if (quality == PYSP_QUALITY_FAST) {
         LAUNCH_TRY(launch_eag(ctx->stream, src, H, W, wb, M, tail, d_out, &ctx->tl));
     } else if (quality == PYSP_QUALITY_DRAFT) {

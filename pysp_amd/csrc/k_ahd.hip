@@ -12,11 +12,13 @@
 //   then, for the horizontal and the vertical candidate in turn (one code path, unrolled twice):
 //   P2  one thread per quad (halo 1 quad): high-pass of green, photosite-aware resampling of
 //       R and B, second white balance + float64 CCM + Lab, all in registers; Lab -> LDS
-//   P3  homogeneity vote from a 4x4 Lab window per quad (8-byte LDS reads, edge cells by select), in two row pieces;
+//   P3  homogeneity vote from a 4x4 Lab window per quad (edge cells by select), in two row pieces;
 //       the Lab buffer is its own LDS section (round 3), the vertical green planes are built into the plane buffer meanwhile
 //   finally
 //   P4  3x3 box of the packed votes (integer), H/V selection (both candidates still in registers), optional colour tail, store.
-// 71 VGPRs; 25.5 KB of LDS with the Lab grid of mode 1 (read from L2): six workgroups per CU (round 2: 92 VGPRs, 20.6 KB, five).
+// Round 4, Lab mode 1: the Lab buffer holds 8-byte cells { L, a' | b' << 16 } (the interpolated table integers), the chroma distances of the vote are integer
+// (v_pk_sub_i16 + v_dot2), exact while below 2^24, with a wave-uniform float redo otherwise: 70 VGPRs, 20.8 KB of LDS, SEVEN workgroups per CU
+// (round 3: 71 VGPRs, 25.5 KB, six; round 2: 92 VGPRs, 20.6 KB, five).  Template value LAB = 2 keeps round 3's float planes (pysp_ctx_set_lab_layout).
 // -DAHD_TQX / -DAHD_TQY / -DAHD_QPT build the other tile shapes and the two-quads-per-thread form measured in DESIGN.md 7.0 (c).
 // Image-border rules (three of them coexist) are applied at true image edges only.
 #include <type_traits>
@@ -502,17 +504,19 @@ struct AhdParams {
     int hdr;
     int tail;            // colour tail applied to the selected pixel (only when no median stage follows)
     Ccm ccm;
+    unsigned* float_form_tiles;   // packed Lab layout only, may be NULL: two cumulative counters -- [0] += 1 per workgroup in which some wave had to redo its votes in the float form, [1] += tiles of the launch
 };
 
 // TINY: quarter planes narrower than 4 need the general (looping) border functions.
 // HDR (image.get_hdr(), ahd.py:52-59) is a template parameter because its literal-vote path for non-finite luma costs registers.
 // TAIL: a colour tail may follow the selection (only when no median stage does); the instance without it is the benchmark's.
 //
-// LDS (round 3 layout, 25.5 KB with the Lab grid of mode 1: SIX workgroups per CU):
+// LDS (20.8 KB with the packed Lab cells of round 4: SEVEN workgroups per CU; 25.5 KB with three float planes: six):
 //   mw   [4][MWY][MWX]  white-balanced mosaic planes, alive until the vertical green planes are built; the packed vote map lies over them afterwards
 //   gq   [4][GY][GX]    green at R / B sites and the colour differences of ONE direction at a time (horizontal first, vertical built while the
 //                       horizontal votes run)
-//   lab  [3][LPR][LPS]  Lab of one direction, written by the thread that computes it, straight from its registers (no overlay, no staging barrier)
+//   lab  [LPR][LPS] cells of { L, a' | b' << 16 } (LAB = 1) or [3][LPR][LPS] floats (LAB = 0, 2): Lab of one direction, written by the thread that computes
+//                       it, straight from its registers (no overlay, no staging barrier)
 // Round 2 laid the Lab buffer over the mosaic and horizontal planes (20.6 KB, five workgroups per CU limited by 92 VGPRs): every thread then had to
 // hold the twelve Lab values of its quad across a barrier, and the eight green samples of its window across both directions.  Measured on MI355X
 // (tools/ab_bench.sh, LDS padding): five -> four workgroups per CU costs this kernel 9 %, four -> three 24 %: it is latency-bound, occupancy is the lever.
@@ -540,7 +544,7 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
 
     const int tid = threadIdx.x;
     AHD_STAMP(0);
-    if (HDR && tid < 2) s_nonfinite[tid] = 0;                                   // (the first barrier below orders it before any P2)
+    if (tid < 3) s_nonfinite[tid] = 0;                                          // (the first barrier below orders it before any P2); [2]: some wave took the float form of the vote
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const double* M = p.ccm.m;
@@ -815,6 +819,7 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
                 }
 #ifndef AHD_I16_NOGUARD          // (timing experiment only: wrong on hard colour noise)
                 if (big != 0) {          // uniform over the wave; never taken on ordinary content
+                    s_nonfinite[2] = 1;                                                // (read after the barrier that precedes P4)
                     asm volatile("" ::: "memory");                                     // fresh loads: nothing of the integer form stays live into this path
 #ifdef AHD_I16_FAST_FLOAT_FORM          // (A/B only: 78 VGPRs, six waves per SIMD -- the kernel keeps its seventh wave with the frugal form below)
                     // round 3's float vote (pair sharing, two window pieces) on converted values: the integer form's registers are dead here
@@ -880,6 +885,10 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
     AHD_STAMP(11);             // P3(V) done
     __syncthreads();
     AHD_STAMP(12);
+    if (I16 && tid == 0 && p.float_form_tiles != nullptr) {          // two cumulative words the host's layout policy samples: tiles that needed the float form, tiles launched
+        if (s_nonfinite[2] != 0) atomicAdd(p.float_form_tiles, 1u);
+        if (tbx == 0 && tby == 0) atomicAdd(p.float_form_tiles + 1, (unsigned)(((w + TQX - 1) / TQX) * ((h + TQY - 1) / TQY)));
+    }
 
     // ---- P4: 3x3 box (cv2.blur, REFLECT_101; integer sums order like the float means), select, store
 #pragma unroll
@@ -928,7 +937,7 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
     if (p.H < 0) s_pad[threadIdx.x] = 1.0f;
 #endif
     __shared__ float4 s_labtab[LAB == 0 ? LAB_SLOTS : 1];                    // 12 KB of closed-form tables (Lab mode 0 only; mode 1 reads its grid from L2)
-    __shared__ int s_nonfinite[2];
+    __shared__ int s_nonfinite[3];
     int tbx, tby;
     xcd_tile(tbx, tby);
     ahd_select_tile<TINY, U16, HDR, LAB, TAIL>(p, tbx, tby, planes, s_labtab, s_nonfinite);
@@ -1245,7 +1254,7 @@ __global__ void __launch_bounds__(NT_A, 1) k_ahd_fused(AhdParams a, MedParams m,
     static_assert(NT_A == NT_B, "one workgroup size for both roles");
     constexpr int NF = SelLds<1>::N > MED_LDS_FLOATS ? SelLds<1>::N : MED_LDS_FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[NF];
-    __shared__ int s_nonfinite[2];
+    __shared__ int s_nonfinite[3];
     const unsigned lin = blockIdx.x, xcd = lin & 7u, j = lin >> 3;
     const unsigned qs = pl.sel_n >> 3, rs = pl.sel_n & 7u, ns = qs + (xcd < rs ? 1u : 0u), s0 = xcd * qs + (xcd < rs ? xcd : rs);
     const unsigned qm = pl.med_n >> 3, rm = pl.med_n & 7u, nm = qm + (xcd < rm ? 1u : 0u), m0 = xcd * qm + (xcd < rm ? xcd : rm);
@@ -1263,8 +1272,10 @@ __global__ void __launch_bounds__(NT_A, 1) k_ahd_fused(AhdParams a, MedParams m,
 
 // ------------------------------------------------------------------------------------------------
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
-               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl, int lab_planes) {
+               int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl, int lab_planes,
+               unsigned* d_float_form_tiles) {
     AhdParams a;
+    a.float_form_tiles = d_float_form_tiles;
     a.labtab = reinterpret_cast<const float4*>(d_labtab);
     a.lablut = reinterpret_cast<const uint4*>(d_lablut);
     a.src = src; a.H = H; a.W = W; a.hdr = hdr;
@@ -1312,12 +1323,14 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
 // A batch of n frames through AHD with ONE median stage, Lab mode 1, frames of at least 8 x 8 px: n + 1 launches instead of 2 n -- select(frame 0), then
 // n - 1 role-interleaved launches (select tiles of frame i + 1 and median tiles of frame i in one grid, k_ahd_fused), then median(frame n - 1).  The
 // intermediate RGB images alternate between d_tmp0 and d_tmp1.  Same kernels' code, same results as n calls of launch_ahd.
+int ahd_select_tiles(int H, int W) { return ((W / 2 + TQX - 1) / TQX) * ((H / 2 + TQY - 1) / TQY); }
 bool ahd_pipelined_ok(int n, int H, int W, int stages, const void* d_lablut) { return n >= 2 && stages == 1 && d_lablut != nullptr && H / 2 >= 4 && W / 2 >= 4; }
 int launch_ahd_pipelined(hipStream_t st, const MosaicSrc* srcs, int n, int H, int W, const float wb[3], const double M[9], int hdr, int tail,
                          float* const* d_outs, float* d_tmp0, float* d_tmp1, const void* d_lablut, Timeline* tl) {
     if (!ahd_pipelined_ok(n, H, W, 1, d_lablut)) return -3;
     AhdParams a;
     a.labtab = nullptr;
+    a.float_form_tiles = nullptr;
     a.lablut = reinterpret_cast<const uint4*>(d_lablut);
     a.H = H; a.W = W; a.hdr = hdr; a.tail = 0;
     for (int i = 0; i < 3; i++) a.wb[i] = wb[i];

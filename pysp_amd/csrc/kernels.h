@@ -37,7 +37,9 @@ int launch_colour_tail(hipStream_t st, const float* in, size_t npx, const double
 // d_tmp0/d_tmp1 are (H,W,3) scratch images (only needed when stages >= 1 / >= 2).
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut /* Lab mode 1, else NULL */,
-               Timeline* tl = nullptr, int lab_planes = 0 /* Lab mode 1: float Lab planes and float votes (round 3's form) instead of packed cells */);
+               Timeline* tl = nullptr, int lab_planes = 0 /* Lab mode 1: float Lab planes and float votes (round 3's form) instead of packed cells */,
+               unsigned* d_float_form_tiles = nullptr /* packed form: device counter, +1 per tile in which a wave redid its votes in float arithmetic */);
+int ahd_select_tiles(int H, int W);   // workgroups of one k_ahd_select launch
 
 // A batch of n frames through AHD with one median stage (Lab mode 1): n + 1 launches, select tiles of frame i + 1 and median tiles of frame i sharing one grid
 // (role-interleaved kernel, k_ahd.hip).  ahd_pipelined_ok says whether the batch qualifies; the caller falls back to n calls of launch_ahd otherwise.

@@ -277,7 +277,7 @@ def test_lab_layouts_agree_on_any_content(orc):
     from pysp_amd.synth import random_frame, rggb_frame
     wb, M = _wbM(orc)
     pipe = DevicePipeline(0)
-    assert pipe.ctx.get_lab_layout() == 0
+    assert pipe.ctx.get_lab_layout() == -1 and pipe.ctx.lab_layout_in_use() == 0          # automatic, starting with the packed form
     H, W = 180, 260
     mixed = rggb_frame(H, W, 1000).copy()
     mixed[:, W // 2:] = random_frame(H, W, 8)[:, W // 2:]
@@ -294,5 +294,20 @@ def test_lab_layouts_agree_on_any_content(orc):
                     assert np.array_equal(got, r, equal_nan=True), (hdr, layout)
         with pytest.raises(ValueError):
             pipe.ctx.set_lab_layout(2)
+        # the automatic policy: pure noise sends (nearly) every tile through the float form -> after a sample (16 launches) has landed the context launches the
+        # planes form; it holds it for 256 launches whatever the content, then probes with the packed form again and stays there on the benchmark scene
+        pipe.ctx.set_lab_layout("auto")
+        d_noise, d_scene = torch.from_numpy(frames[1]).cuda(), torch.from_numpy(frames[0]).cuda()
+        for i in range(40):
+            got = pipe.demosaic(d_noise, wb, M, _lib.QUALITY_BEST, False, 1)
+            if i % 8 == 0:
+                pipe.sync()
+        assert np.array_equal(got.cpu().numpy(), orc.demosaic_ahd(frames[1], wb, M, False, 1))
+        assert pipe.ctx.lab_layout_in_use() == 1
+        for i in range(300):
+            got = pipe.demosaic(d_scene, wb, M, _lib.QUALITY_BEST, False, 1)
+            if i % 8 == 0:
+                pipe.sync()
+        assert pipe.ctx.lab_layout_in_use() == 0 and np.array_equal(got.cpu().numpy(), orc.demosaic_ahd(frames[0], wb, M, False, 1))
     finally:
-        pipe.ctx.set_lab_layout(0)
+        pipe.ctx.set_lab_layout("auto")

@@ -3,7 +3,7 @@
 #   bash tools/collect_profiles.sh r3      (through gpurun; results under gpurun_out/<tag>_final/)
 # rocprofv3 runs the program itself (python3 bench.py ...), never a shell or env wrapper; --pmc passes are separate from the stats pass.
 set -o pipefail
-tag=${1:-r3}
+tag=${1:-r4}
 root=$(pwd)
 out=$root/gpurun_out/${tag}_final
 mkdir -p "$out"
@@ -23,6 +23,9 @@ echo "stats done"
 for w in ahd24b ahd24u16 eag24ccm draft12 cfg3; do one --workload $w >> "$out/workloads.jsonl"; done
 for w in eag24 eag24ccmu16 eag24raw draft12ccm draft12raw fuse45 warp100 cfg5; do one --workload $w --no-cpu-baseline >> "$out/workloads.jsonl"; done
 one --lab-mode closed_form --no-cpu-baseline >> "$out/workloads.jsonl"
+# the Lab layouts of the select kernel (round 4): round 3's float planes on the scene; pure noise with the automatic policy, the packed form and the planes form
+one --lab-layout planes --no-cpu-baseline >> "$out/workloads.jsonl"
+for l in auto packed planes; do one --scene noise --lab-layout $l --no-cpu-baseline >> "$out/workloads.jsonl"; done
 one --gpus 2 --backend gloo --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline >> "$out/workloads.jsonl"
 one --gpus 2 --backend gloo --workload cfg3 --steps 20 --warmup 3 --no-cpu-baseline >> "$out/workloads.jsonl"
 echo "workloads done"
@@ -39,5 +42,6 @@ python3 "$root/tools/config_time.py" > "$out/config_time.log" 2>&1
 python3 "$root/tests/ref_native_time.py" gpu > "$out/native_units_gpu.log" 2>&1
 # 6. the microbenchmarks behind the issue-cost model and the stream ceilings (binaries built by `make -C tools` / hipcc before the call)
 [ -x "$root/tools/ubench_valu3.bin" ] && "$root/tools/ubench_valu3.bin" > "$out/ubench_valu.log" 2>&1
+[ -x "$root/tools/ubench_valu4.bin" ] && timeout -k 10 150 "$root/tools/ubench_valu4.bin" > "$out/ubench_pairs.log" 2>&1
 [ -x "$root/tools/ubench_stream.bin" ] && "$root/tools/ubench_stream.bin" > "$out/ubench_stream.log" 2>&1
 echo "all done"
