@@ -82,8 +82,8 @@ int pysp_lab_cv410_lut(int16_t *out);
  * pysp_ctx_get_lab_lut copies the table in use into out[33*33*33*3]. */
 int pysp_ctx_set_lab_lut(pysp_ctx *ctx, const int16_t *grid);
 /* How the AHD select kernel keeps the Lab values of mode 1 (a performance choice: both forms return the same bits, debayer/ahd_homogeneity_cython.pyx:47-58):
- *    0  packed cells { L, a'|b'<<16 }, chroma distances on the table's integers, seven workgroups per CU -- 3 % faster on ordinary content; a wave that
- *       meets a chroma step of 64 Lab units or more between neighbouring pixels redoes its votes in float32 arithmetic (pure colour noise: +17 %);
+ *    0  packed cells { L, a'|b'<<16 }, chroma distances on the table's integers, seven workgroups per CU -- the select kernel 2 % faster on ordinary content; a wave that
+ *       meets a chroma step of 64 Lab units or more between neighbouring pixels redoes its votes in float32 arithmetic (pure colour noise: +16 %);
  *    1  three float planes and float votes (round 3's kernel): the same speed on any content;
  *   -1  (default) automatic: the packed kernel counts the tiles that needed the float form; when more than a quarter of the tiles of a sample did, the
  *       context launches the planes form for the next 256 frames and then probes again.  No host wait is involved (one 8-byte copy per 16 launches,

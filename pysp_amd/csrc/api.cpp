@@ -65,7 +65,7 @@ struct pysp_ctx {
     int lab_mode = 1;            // 1 (default): OpenCV 4.10's LUT + trilinear restatement; 0: closed-form Lab (tables above)
     void* lablut = nullptr;      // mode 1: [34][34][34] x 64 B grid (devmath.h)
     // Lab mode 1 inside the AHD select kernel (pysp_ctx_set_lab_layout): -1 automatic (default), 0 packed Lab cells + integer chroma votes, 1 float planes + float
-    // votes.  Same bits either way.  The packed form is 2-3 % faster unless the content makes its waves redo their votes in float arithmetic (neighbouring pixels
+    // votes.  Same bits either way.  The packed form is 2 % faster unless the content makes its waves redo their votes in float arithmetic (neighbouring pixels
     // 64 Lab units of chroma apart: synthetic colour noise), where it is 16 % slower.  Automatic: the packed kernel keeps two cumulative device counters (tiles in
     // which that happened, tiles launched); every LAYOUT_SAMPLE-th packed launch ONE 8-byte copy to page-locked memory is enqueued behind the kernels (nobody
     // waits for it).  States: PACKED -- a new sample in which more than a quarter of the tiles took the float form starts a HOLD of `layout_hold_len` planes

@@ -107,6 +107,10 @@ def record_calls(cv2):
     out["filter2d"] = np.stack([cv2.filter2D(r, -1, k) for k in inp["kernels"]])
     for k in LAB_INPUTS:
         out[k + "_out"] = cv2.cvtColor(inp[k], cv2.COLOR_RGB2LAB)
+    # OpenCV's own int16 table, ready for pysp_ctx_set_lab_lut / oracle.set_cv410_lut / cv2_restated.set_cv410_lab_lut (and whether the node outputs had the LUT path's form at all)
+    grid, exact = lab_grid_from_nodes(out["lab_nodes_out"])
+    out["lab_grid_s16"] = grid
+    out["lab_grid_exact"] = np.array(exact)
     out["blur"] = cv2.blur(inp["vote_map"], (3, 3))
     out["median5"] = cv2.medianBlur(inp["chroma_diff"], 5)
     out["resize"] = cv2.resize(inp["quarter_rgb"], (W, H))
