@@ -568,6 +568,10 @@ def main() -> None:
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"
                         else "frame-parallel, no data-path collective; WB/CCM block broadcast from rank 0 (RCCL) per batch")}
     cfg.update(extra_cfg)
+    try:
+        cfg["lab_layout_in_use_at_end"] = ["packed", "planes"][kernel_ctx.lab_layout_in_use()]      # what the automatic policy had settled on
+    except Exception:
+        pass
     if args.scene != "synthetic":
         cfg["scene"] = "pure uniform noise (rng.random), not the SURVEY 8d scene"
     if args.frame_size:
