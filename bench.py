@@ -421,9 +421,14 @@ def main() -> None:
     per_kernel = {k: float(np.mean(v)) for k, v in samples.items()}
     launches = {k: len(v) for k, v in samples.items()}
 
+    # the last collective is behind us: EVERY rank leaves the process group here, together -- rank 0 then verifies and prints on its own (its verify leg takes
+    # seconds of CPU oracle time; tearing the group down afterwards would have rank 0 destroy an RCCL communicator whose peers left long ago)
+    backend_name = ("rccl" if args.backend == "nccl" else "gloo") if dist is not None else None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -563,7 +568,7 @@ def main() -> None:
             cpu_baseline = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"unavailable: {exc!r}"}
 
     cfg = {"workload": desc, "H": H, "W": W, "lab_mode": args.lab_mode, "lab_layout": args.lab_layout, "frames_per_rank_resident": len(frames), "streams_per_rank": n_streams,
-           "backend": ("rccl" if args.backend == "nccl" else "gloo") if dist is not None else None,
+           "backend": backend_name,
            "untimed_settle_steps": settle_steps,
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"
                         else "frame-parallel, no data-path collective; WB/CCM block broadcast from rank 0 (RCCL) per batch")}
@@ -588,8 +593,6 @@ def main() -> None:
     if rank_ms is not None:
         line["ranks_ms_per_step"] = rank_ms
     print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
     # every workload verified above is documented as BIT-exact against the oracle: any differing value fails the run (the gate
     # used to let a 1-ULP regression through with exit code 0)
     if verify is not None and not (verify["bit_exact"] and verify.get("bit_exact_demosaic", True)):

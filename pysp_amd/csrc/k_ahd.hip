@@ -35,6 +35,10 @@ namespace {
 constexpr int TQX = AHD_TQX, TQY = AHD_TQY;       // output quads per tile; the 1-quad halo makes (TQX+2)x(TQY+2) threads
 constexpr int MWX = TQX + 6, MWY = TQY + 6;       // mosaic planes, halo 3 quads
 constexpr int GX = TQX + 4, GY = TQY + 4;         // green / difference planes, halo 2 quads
+#ifndef AHD_LANES8
+#define AHD_LANES8 0                              // experiment (round 4): a wave covers 8 x 8 quads instead of 4 rows of 16, and the planes get a row stride of 24 floats,
+#endif                                            // so that the 4-byte window reads of P2 meet no LDS bank twice (rows at bank offsets 0, 24, 48, 8, 32, 56, 16, 40)
+constexpr int GXS = AHD_LANES8 ? 24 : GX;         // row stride of the green / difference planes
 constexpr int LQX = TQX + 2, LQY = TQY + 2;       // Lab region in quads (halo 1 quad = 2 px)
 constexpr int LPS = 2 * LQX + 2, LPR = 2 * LQY + 2;  // Lab plane stride / rows: region + 1 px guard ring (34 x 34)
 constexpr int MPS = 2 * TQX + 4, MPR = 2 * TQY + 2;  // packed vote map (halo 1 px), stride 32 (8-byte aligned rows)
@@ -523,7 +527,7 @@ struct AhdParams {
 // LDS floats of the select tile: the three sections below (+ 2: the last window row of the last Lab plane is read, never used, one row past LPR)
 template <int LAB> struct SelLds {
     static constexpr bool I16 = LAB == 1 && AHD_I16 != 0;      // packed Lab cells { L, a' | b' << 16 } and integer chroma votes (round 4)
-    static constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GX, NLAB = (I16 ? 2 : 3) * LPR * LPS, N = NMW + NGQ + NLAB + 2;
+    static constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GXS, NLAB = (I16 ? 2 : 3) * LPR * LPS, N = NMW + NGQ + NLAB + 2;
 };
 // One 28x28 px tile of the select kernel.  The body is a device function so that the stand-alone kernel (k_ahd_select: one tile per workgroup, XCD-aware
 // order) and the role-interleaved kernel (k_ahd_fused: select tiles of one frame and median tiles of the previous one in ONE grid) share it.
@@ -630,8 +634,9 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
                 gr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
                 gb = (((MWAT(P_B, a - 1, c) * AH0 + MWAT(P_G1, a, c) * AH1) + bc * AH2) + MWAT(P_G1, a + 1, c) * AH1) + MWAT(P_B, a + 1, c) * AH0;
             }
-            gq[0 * GY * GX + idx] = gr; gq[1 * GY * GX + idx] = gb;
-            gq[2 * GY * GX + idx] = rc - gr; gq[3 * GY * GX + idx] = bc - gb;
+            const int gi = gy * GXS + gx;
+            gq[0 * GY * GXS + gi] = gr; gq[1 * GY * GXS + gi] = gb;
+            gq[2 * GY * GXS + gi] = rc - gr; gq[3 * GY * GXS + gi] = bc - gb;
         }
     };
     green_planes(0);
@@ -644,7 +649,11 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
     auto quad = [&](const int q) {
         Quad c;
         const int idx = tid + q * NT_A;
-        c.lqy = idx / LQX; c.lqx = idx - c.lqy * LQX;
+        if (AHD_LANES8 && QPT == 1 && LQX == 16 && LQY == 16) {      // wave w covers the 8 x 8 quads of quadrant (w / 2, w % 2)
+            c.lqy = ((idx >> 7) << 3) + ((idx >> 3) & 7); c.lqx = (((idx >> 6) & 1) << 3) + (idx & 7);
+        } else {
+            c.lqy = idx / LQX; c.lqx = idx - c.lqy * LQX;
+        }
         const int qi = tq0y - 1 + c.lqy, qj = tq0x - 1 + c.lqx;
         c.active = qi >= 0 && qi < h && qj >= 0 && qj < w;
         c.at_top = qi == 0; c.at_bot = qi == h - 1; c.at_left = qj == 0; c.at_right = qj == w - 1;
@@ -672,8 +681,8 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
         auto candidate = [&](const int q) {
             const Quad& c = qc[q];
             const int gy = c.gy, gx = c.gx, my = c.my, mx = c.mx;
-            const float* gR = gq, *gB = gq + GY * GX, *dR = gq + 2 * GY * GX, *dB = gq + 3 * GY * GX;
-            Win3 wgr = load_win<GX>(gR, gy, gx), wgb = load_win<GX>(gB, gy, gx);
+            const float* gR = gq, *gB = gq + GY * GXS, *dR = gq + 2 * GY * GXS, *dB = gq + 3 * GY * GXS;
+            Win3 wgr = load_win<GXS>(gR, gy, gx), wgb = load_win<GXS>(gB, gy, gx);
             // the quad's own two green samples are the same in both candidates: the vertical pass takes them from the horizontal candidate's registers
             const float g1_c = dir == 0 ? MWAT(P_G1, my, mx) : rgbh[q][1][1], g2_c = dir == 0 ? MWAT(P_G2, my, mx) : rgbh[q][2][1];
             // full-resolution green, rows 2qi-1..2qi+2, cols 2qj-1..2qj+2
@@ -698,11 +707,11 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
             highpass_quad(Wn, hf);
             float fg[4], fd[4];
             filt_base_tl(wgr, fg);
-            { Win3 wd = load_win<GX>(dR, gy, gx); filt_base_tl(wd, fd); }
+            { Win3 wd = load_win<GXS>(dR, gy, gx); filt_base_tl(wd, fd); }
 #pragma unroll
             for (int k = 0; k < 4; k++) rr[q][k] = fd[k] + (fg[k] + hf[k]);      // eag.py:141,143
             filt_base_br(wgb, fg);
-            { Win3 wd = load_win<GX>(dB, gy, gx); filt_base_br(wd, fd); }
+            { Win3 wd = load_win<GXS>(dB, gy, gx); filt_base_br(wd, fd); }
 #pragma unroll
             for (int k = 0; k < 4; k++) bb[q][k] = fd[k] + (fg[k] + hf[k]);
             gg[q][0] = wgr.v[1][1]; gg[q][1] = g1_c; gg[q][2] = g2_c; gg[q][3] = wgb.v[1][1];
