@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity run (bit-exact): python tests/fuzz_parity.py [seconds] [seed]
 Test infrastructure (it calls the CPU oracle); a 10-second slice of it runs inside the GPU suite (test_gpu_parity.py::test_fuzz_slice).
 Random even frame sizes, value distributions (uniform, heavy-tailed, saturated, zeros, negatives, tiny), qualities, HDR flag,
-post-process stage counts, colour tails, uint16 input, CA removal, raw fusion, WarpRectilinear (fused kernel vs its own tables through the oracle remap).  Stops at the first mismatch with a reproducer line."""
+post-process stage counts, colour tails, Lab layout / Lab mode of the context, uint16 input, CA removal, raw fusion, WarpRectilinear (fused kernel vs its own tables through the oracle remap).  Stops at the first mismatch with a reproducer line."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,6 +42,7 @@ def frame(rng, H, W):
 t_end = time.time() + budget
 n = 0
 counts = {}
+cur_layout = None
 while time.time() < t_end:
     seed = seed0 + n
     rng = np.random.default_rng(seed)
@@ -57,18 +58,26 @@ while time.time() < t_end:
     M = M0 * rng.uniform(0.8, 1.2, (3, 3)) if rng.random() < 0.5 else M0
     case = int(rng.integers(0, 7))
     d = torch.from_numpy(bay).cuda()
+    # context switches of the AHD kernels (round 4): Lab layout automatic / packed cells / float planes -- same bits in every one -- and now and then the
+    # closed-form Lab metric (mode 0) on both sides.  From its own generator, so that the case streams of earlier seeds stay what they were.
+    # The layout changes every 64 cases only (setting it restarts the automatic policy, which needs 16 launches per sample to move at all).
+    layout = ("auto", "packed", "planes", "auto")[int(np.random.default_rng((seed // 64) ^ 0x5EED).integers(0, 4))]
+    if layout != cur_layout:
+        pipe.ctx.set_lab_layout(layout); cur_layout = layout
+    lab_mode = 0 if np.random.default_rng(seed ^ 0x5EED).random() < 0.1 else 1
+    pipe.ctx.set_lab_mode(lab_mode); orc.set_lab_mode(lab_mode)
     if case == 0:      # AHD with stages / hdr
         stages, hdr = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
         if nonfinite: stages = 0
         got = pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, hdr, stages); pipe.sync()
         ref = orc.demosaic_ahd(bay, wb, M, hdr, stages)
-        tag = f"ahd stages={stages} hdr={hdr}"
+        tag = f"ahd stages={stages} hdr={hdr} layout={layout} lab_mode={lab_mode}"
     elif case == 1:    # fused pipeline to sRGB, any quality
         q, stages, hdr, rh = int(rng.integers(0, 3)), int(rng.integers(0, 3)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         if nonfinite: stages = 0
         got = pipe.demosaic_to_srgb(d, wb, M, q, hdr, stages, rh); pipe.sync()
         ref = orc.pipeline_srgb(bay, wb, M, q, hdr, stages, rh)
-        tag = f"srgb q={q} stages={stages} hdr={hdr} reinhard={rh}"
+        tag = f"srgb q={q} stages={stages} hdr={hdr} reinhard={rh} layout={layout} lab_mode={lab_mode}"
     elif case == 2:    # EAG / Draft raw
         q = int(rng.integers(0, 2))
         got = pipe.demosaic(d, wb, M, q, False, 0); pipe.sync()
@@ -80,7 +89,7 @@ while time.time() < t_end:
         q = int(rng.integers(0, 3))
         got = pipe.raw_u16_to_rgb(torch.from_numpy(raw.view(np.int16)).cuda(), black, sat, wb, M, q, 1, 2); pipe.sync()
         ref = orc.pipeline_srgb(orc.bayer_normalize(raw, black, sat), wb, M, q, False, 1, False)
-        tag = f"u16 q={q}"
+        tag = f"u16 q={q} layout={layout} lab_mode={lab_mode}"
     elif case == 4:    # CA removal with random smooth quadrant fields
         if H < 4 or W < 4 or nonfinite:
             n += 1; continue
@@ -133,6 +142,9 @@ while time.time() < t_end:
         print(f"MISMATCH seed={seed} {H}x{W} {tag}: {len(bad)} values, first at {bad[0]}: gpu {g[tuple(bad[0])]!r} oracle {ref[tuple(bad[0])]!r}")
         sys.exit(1)
     counts[tag.split()[0]] = counts.get(tag.split()[0], 0) + 1
+    if tag.split()[0] in ("ahd", "srgb", "u16") and lab_mode == 1:
+        k = "planes_kernel_next" if pipe.ctx.lab_layout_in_use() == 1 else "packed_kernel_next"      # what the policy / the switch selects after this case
+        counts[k] = counts.get(k, 0) + 1
     n += 1
     if n % 200 == 0:
         print(f"{n} cases ok, {counts}", flush=True)
