@@ -153,7 +153,14 @@ DEVI void rgb2lab_cv410_q(const uint4* __restrict__ lut, float R, float G, float
     const unsigned fx = (bx >> 5) & 15u, fy = (by >> 5) & 15u, fz = (bz >> 5) & 15u;
     const unsigned tx = (bx >> 9) & 63u, ty = (by >> 9) & 63u, tz = (bz >> 9) & 63u;
     // 24-bit multiplies throughout (v_mul_u32_u24 / v_mad_u32_u24 issue at the full rate, v_mul_lo_u32 at a quarter of it)
+#ifdef LAB_ADDR_DOT2
+    // cell index (tz * 34 + ty) * 34 + tx as ONE v_dot2_u32_u16 of (tz, ty) with (34 * 34, 34), tx as the accumulator (round 4: one multiplier-class instruction instead of two)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const unsigned cell = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, ((by << 7) & 0x3F0000u) | tz), __builtin_bit_cast(us2, (unsigned)(CV410_DIM * CV410_DIM) | ((unsigned)CV410_DIM << 16)), tx, false);
+    const uint4* e = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lut) + (cell << 6));      // 32-bit byte offset (the table is 2.5 MB): (scalar base, vector offset) loads
+#else
     const uint4* e = lut + 4u * (__umul24(__umul24(tz, CV410_DIM) + ty, CV410_DIM) + tx);
+#endif
     const uint4 q0 = e[0], q1 = e[1], q2 = e[2];      // 12 dwords of one 64-byte line: (dz, dy) = (0,0), (0,1), (1,0), (1,1), each (L, a, b) as x pairs
     const unsigned wx = (16u - fx) | (fx << 16);                             // both x weights in one register; times <= 256 stays inside each half
     // six products instead of eight: the x pair times the two z factors first (<= 256 per half), then times the two y factors (<= 4096 per half)

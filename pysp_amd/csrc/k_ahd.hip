@@ -615,6 +615,50 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
 
 #define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
     // ---- P1(dir): directional green at R/B sites (ahd.py:97-102) and D = sub - g (eag.py:142) of ONE direction into gq
+#ifdef AHD_P1_OWN_ELEMENT      // experiment (round 4): measured -0.2 % on the select kernel, inside the noise; off
+    auto green_planes = [&](const int dir) {
+        auto body = [&](const int gy, const int gx, const int a, const int c) {
+            const float rc = MWAT(P_R, a, c), bc = MWAT(P_B, a, c);
+            float gr, gb;
+            if (dir == 0) {
+                gr = (((MWAT(P_R, a, c - 1) * AH0 + MWAT(P_G1, a, c - 1) * AH1) + rc * AH2) + MWAT(P_G1, a, c) * AH1) + MWAT(P_R, a, c + 1) * AH0;
+                gb = (((MWAT(P_B, a, c - 1) * AH0 + MWAT(P_G2, a, c) * AH1) + bc * AH2) + MWAT(P_G2, a, c + 1) * AH1) + MWAT(P_B, a, c + 1) * AH0;
+            } else {
+                gr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
+                gb = (((MWAT(P_B, a - 1, c) * AH0 + MWAT(P_G1, a, c) * AH1) + bc * AH2) + MWAT(P_G1, a + 1, c) * AH1) + MWAT(P_B, a + 1, c) * AH0;
+            }
+            const int gi = gy * GXS + gx;
+            gq[0 * GY * GXS + gi] = gr; gq[1 * GY * GXS + gi] = gb;
+            gq[2 * GY * GXS + gi] = rc - gr; gq[3 * GY * GXS + gi] = bc - gb;
+        };
+        // two copies of the body on purpose: the interior tiles' addresses are tid-derived constants, the border tiles' come out of the reflections
+        auto element = [&](const int gy, const int gx) {
+            if (inside) { body(gy, gx, gy + 1, gx + 1); return; }
+            const int ri = TINY ? b_101(tq0y - 2 + gy, h) : b_1011(tq0y - 2 + gy, h);   // REFLECT_101 on the quarter plane
+            const int rj = TINY ? b_101(tq0x - 2 + gx, w) : b_1011(tq0x - 2 + gx, w);
+            const int a = ri - (tq0y - 3), c = rj - (tq0x - 3);
+            if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) return;                   // never consumed by a valid output
+            body(gy, gx, a, c);
+        };
+        if constexpr (QPT == 1 && LQX == 16 && LQY == 16 && !AHD_LANES8) {
+            // Round 4: every thread its own quad's element of the 18 x 18 plane (row tid / 16 + 1, column tid % 16 + 1: shifts, and offsets that differ from the thread's
+            // other LDS addresses by constants), then the 68 ring elements on the first 68 lanes -- the two waves that ran the second trip of the loop below anyway.
+            // (Before: idx / 18 by a 24-bit multiply, its remainder by a second one and the row offset by a v_mul_lo_u32, per trip and direction.)
+            static_assert(GY == LQY + 2 && GX == LQX + 2, "interior + ring");
+            element((tid >> 4) + 1, (tid & 15) + 1);
+            if (tid < 2 * GX + 2 * LQY) {
+                int gy, gx;
+                if (tid < 2 * GX) { const bool bot = tid >= GX; gy = bot ? GY - 1 : 0; gx = tid - (bot ? GX : 0); }       // top row, bottom row
+                else { const int q = tid - 2 * GX; gy = (q & (LQY - 1)) + 1; gx = q >= LQY ? GX - 1 : 0; }                // left column, right column
+                element(gy, gx);
+            }
+        } else
+        for (int idx = tid; idx < GY * GX; idx += NT_A) {
+            const int gy = idx / GX;
+            element(gy, idx - gy * GX);
+        }
+    };
+#else
     auto green_planes = [&](const int dir) {
         for (int idx = tid; idx < GY * GX; idx += NT_A) {
             int gy = idx / GX, gx = idx - gy * GX;
@@ -639,6 +683,7 @@ DEVI void ahd_select_tile(const AhdParams& p, const int tbx, const int tby, floa
             gq[2 * GY * GXS + gi] = rc - gr; gq[3 * GY * GXS + gi] = bc - gb;
         }
     };
+#endif
     green_planes(0);
     AHD_STAMP(3);      // P1(H) done
     __syncthreads();
@@ -1044,6 +1089,40 @@ DEVI void ahd_median_tile(const MedParams& p, const int tbx, const int tby, floa
         // uniform 64-bit tile origin + tile-local 32-bit byte offset per lane: (scalar base, vector offset) accesses, no 64-bit vector arithmetic
         const char* const tile = reinterpret_cast<const char*>(p.in + ((size_t)(ty0 - 4) * W + (tx0 - 4)) * 3);
         float4 t[NLG][3];
+#ifdef MED_LOADER_INCREMENTAL
+        // Group gi = tid + 256 k of the 36 x 17 groups (round 4): row and column by ONE division, for k = 0; 256 = 15 * 17 + 1, so the next group lies 15 rows down and
+        // one column right, with a wrap into the following row -- uniform byte steps and a compare per pass.  A plane row is exactly 17 groups (B4X = 68 floats), so the
+        // LDS address is linear in gi: 16 * tid plus immediates.  (Before: a division, two 24-bit multiplies and a 64-bit mad per pass and side -- 21 multiplier-class
+        // instructions of the loader's 100.)
+        static_assert(B4X == 4 * GPR && NT_B == 15 * GPR + 1 && NLG == 3 && NG - 2 * NT_B > 0, "the incremental form below is spelled for 36 x 17 groups and 256 threads");
+        const unsigned r0 = (unsigned)tid / (unsigned)GPR, g0 = (unsigned)tid - r0 * (unsigned)GPR;
+        const unsigned off0 = __umul24(r0, rowbytes) + __umul24(g0, 48u);
+        const unsigned step = 15u * rowbytes + 48u, wrap = rowbytes - 48u * (unsigned)GPR;                       // uniform
+        const unsigned off1 = off0 + step + (g0 >= (unsigned)GPR - 1u ? wrap : 0u);
+        unsigned off2 = off0 + 2u * step + (g0 >= (unsigned)GPR - 2u ? wrap : 0u);
+        const bool third = tid < NG - 2 * NT_B;
+        if (!third) off2 = off0;                                                                                   // lanes without a third group load their first one again
+        {
+            const float4* s = reinterpret_cast<const float4*>(tile + off0);
+            t[0][0] = s[0]; t[0][1] = s[1]; t[0][2] = s[2];
+            s = reinterpret_cast<const float4*>(tile + off1);
+            t[1][0] = s[0]; t[1][1] = s[1]; t[1][2] = s[2];
+            s = reinterpret_cast<const float4*>(tile + off2);
+            t[2][0] = s[0]; t[2][1] = s[1]; t[2][2] = s[2];
+        }
+        float4* const dg = reinterpret_cast<float4*>(&s_g[0][0]) + tid;
+        float4* const dr = reinterpret_cast<float4*>(&s_drg[0][0]) + tid;
+        float4* const db = reinterpret_cast<float4*>(&s_dbg[0][0]) + tid;
+#pragma unroll
+        for (int k = 0; k < NLG; k++) {
+            if (k < 2 || third) {
+                const float4 a = t[k][0], b = t[k][1], c = t[k][2];      // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+                dg[k * NT_B] = make_float4(a.y, b.x, b.w, c.z);
+                dr[k * NT_B] = make_float4(a.x - a.y, a.w - b.x, b.z - b.w, c.y - c.z);
+                db[k * NT_B] = make_float4(a.z - a.y, b.y - b.x, c.x - b.w, c.w - c.z);
+            }
+        }
+#else
 #pragma unroll
         for (int k = 0; k < NLG; k++) {
             int gi = tid + k * NT_B;
@@ -1063,6 +1142,7 @@ DEVI void ahd_median_tile(const MedParams& p, const int tbx, const int tby, floa
                 *reinterpret_cast<float4*>(&s_dbg[ly][lx]) = make_float4(a.z - a.y, b.y - b.x, c.x - b.w, c.w - c.z);
             }
         }
+#endif
     } else {
         constexpr int NL = (B4Y * B4X + NT_B - 1) / NT_B;
         float tr[NL], tg[NL], tb[NL];
