@@ -58,9 +58,10 @@ WORKLOADS = {
     "fuse45": (5464, 8192, -1, 0, "raw_hdr fuse_exposures_to_raw, 7 x 45MP exposures -> HDR mosaic + count (36 B per output px)"),
     "warp100": (8736, 11648, -2, 0, "100MP RGB, DNG WarpRectilinear per-channel Lanczos-4 remap (24 B/px)"),
     # whole BASELINE configs across the GPUs of a node
-    # the headline path on a batch: frames are independent, so the select tiles of frame i + 1 share a grid with the median tiles of frame i (role-interleaved
-    # launch, pysp_pipeline_batch_dev): one step = `--frames` distinct 24 MP frames in, as many sRGB frames out, one C-ABI call
-    "ahd24b": (4000, 6000, 2, 1, "batch of 24MP RGGB frames per step, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb, one batched call (select of frame i+1 and median stage of frame i share a grid)"),
+    # the headline path on a batch: one step = `--frames` distinct 24 MP frames in, as many sRGB frames out, one C-ABI call (pysp_pipeline_batch_dev).  Frame by
+    # frame unless PYSP_ROLE_INTERLEAVE=1 (then the select tiles of frame i + 1 share a grid with the median tiles of frame i: built in round 4, not faster, off)
+    "ahd24b": (4000, 6000, 2, 1, "batch of 24MP RGGB frames per step, QualityDemosaic.Best (AHD, postprocess_steps=1) + to_lin_srgb + lin_srgb_to_srgb, one batched call "
+                                 "(frame by frame: select + median stage per frame; with PYSP_ROLE_INTERLEAVE=1 the select of frame i+1 and the median stage of frame i share a grid -- config.role_interleave says which ran)"),
     "cfg3": (4000, 6000, 1, 0, "BASELINE config 3: batch of 64 x 24MP frames per 8 GPUs (8 frames per rank per step), EAG + WB + 3x3 CCM, frame-sharded, RCCL parameter broadcast per batch", 1),
     "cfg5": (8736, 11648, 2, 3, "BASELINE config 5: one 100MP frame per step, AHD (postprocess_stages=3) + WarpRectilinear, horizontal bands over the GPUs, RCCL exchange of the warp's source rows", 0),
 }
@@ -87,6 +88,9 @@ def parse_args(argv=None):
                     help="Lab mode 1 inside the AHD select kernel (same results): packed cells + integer chroma votes (fastest on ordinary content), float planes + "
                          "float votes (round 3's form: content-independent speed), or auto (default: packed, switching to planes while the content keeps sending "
                          "waves through the float form of the vote)")
+    ap.add_argument("--select-form", default=None, choices=["tile", "stream"],
+                    help="form of the AHD select kernel (same results): one tile per workgroup, or persistent workgroups streaming down the columns (pysp_ctx_set_select_form); "
+                         "default: the library's")
     ap.add_argument("--exchange", default="needed", choices=["needed", "allgather"], help="cfg5: rows exchanged between the demosaic and the warp")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (under a launcher): exercises the RCCL broadcast / all_reduce / barrier code path on one GPU")
@@ -202,6 +206,8 @@ def main() -> None:
     for c in ctxs:
         c.set_lab_mode(args.lab_mode)
         c.set_lab_layout(args.lab_layout)
+        if args.select_form:
+            c.set_select_form(args.select_form)
     L = _lib.lib()
     alg_bytes_per_px = ALG_BYTES_PER_PX
     frames_per_step = 1
@@ -215,12 +221,16 @@ def main() -> None:
         pipe = DevicePipeline(dev_index)
         pipe.ctx.set_lab_mode(args.lab_mode)
         pipe.ctx.set_lab_layout(args.lab_layout)
+        if args.select_form:
+            pipe.ctx.set_select_form(args.select_form)
         kernel_ctx = pipe.ctx
         nf = args.frames
         frames_per_step = nf
         frames = [torch.from_numpy(rggb_frame(H, W, 1000 + rank * nf + i)).to(dev) for i in range(nf)]      # frame i of rank r: seed 1000 + r*nf + i
         outs = [torch.empty((H, W, 3), dtype=torch.float32, device=dev) for _ in range(nf)]
         extra_cfg = {"frames_per_rank_per_step": nf, "frames_per_step_total": nf * world, "param_broadcast": "once per step (batch), inside the timed region"}
+        if args.workload == "ahd24b":
+            extra_cfg["role_interleave"] = os.environ.get("PYSP_ROLE_INTERLEAVE", "0") == "1"      # which batch path ran
 
         def compute(i: int) -> None:                       # the step's work without its collective (what rank 0 repeats alone when it verifies)
             pipe.batch(frames, state["wb_np"], state["M_np"], quality, False, stages, tail, outs)
@@ -234,6 +244,8 @@ def main() -> None:
         pipe = DevicePipeline(dev_index)
         pipe.ctx.set_lab_mode(args.lab_mode)
         pipe.ctx.set_lab_layout(args.lab_layout)
+        if args.select_form:
+            pipe.ctx.set_select_form(args.select_form)
         kernel_ctx = pipe.ctx
         scaling = "strong"
         plan = BandPlan(H, W, world, rank, stages)
@@ -573,6 +585,10 @@ def main() -> None:
            "sharding": ("horizontal bands of one frame, halo rows from the input, row exchange before the warp" if args.workload == "cfg5"
                         else "frame-parallel, no data-path collective; WB/CCM block broadcast from rank 0 (RCCL) per batch")}
     cfg.update(extra_cfg)
+    try:
+        cfg["select_form"] = ["tile", "stream"][kernel_ctx.get_select_form()]
+    except Exception:
+        pass
     try:
         cfg["lab_layout_in_use_at_end"] = ["packed", "planes"][kernel_ctx.lab_layout_in_use()]      # what the automatic policy had settled on
     except Exception:

@@ -92,12 +92,22 @@ int pysp_ctx_set_lab_lut(pysp_ctx *ctx, const int16_t *grid);
 int pysp_ctx_set_lab_layout(pysp_ctx *ctx, int layout);
 int pysp_ctx_get_lab_layout(pysp_ctx *ctx);
 int pysp_ctx_lab_layout_in_use(pysp_ctx *ctx);
+/* Form of the AHD select kernel (a performance choice, same bits: debayer/ahd.py:97-145, debayer/ahd_homogeneity_cython.pyx:22-58):
+ *    0  one 28x28 px tile per workgroup (16x16 threads, two of the sixteen thread rows and columns are halo);
+ *    1  streaming (round 5): a persistent grid, each workgroup walks down a column of the frame and carries the Lab rows, votes and unselected candidates
+ *       of its last quad row from pass to pass, so that every thread row yields an output row.  Taken for Lab mode 1, packed layout, no HDR metric; any
+ *       other configuration launches form 0.
+ * The default can be preset with the environment variable PYSP_SELECT_FORM (tile / stream). */
+int pysp_ctx_set_select_form(pysp_ctx *ctx, int form);
+int pysp_ctx_get_select_form(pysp_ctx *ctx);
 int pysp_ctx_get_lab_lut(pysp_ctx *ctx, int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
  * the context's stream; waits for completion).  A host call on a frame of more than 4 MP runs in overlapped
  * 256-row bands: the two timing queries then describe the LAST band only (about 1/16 of a 24 MP frame);
- * time whole frames with the *_dev entry points. */
+ * time whole frames with the *_dev entry points.  A host fusion of more exposures than one pass takes
+ * (pysp_fuse_raw_f32 / pysp_fuse_rgb_f32, K > 16 / 12) is timed from its first pass's kernel to its last pass's:
+ * the later passes' uploads lie in between, so that figure is not kernel-only (pysp_ctx_kernel_times lists the passes). */
 int pysp_ctx_last_kernel_ms(pysp_ctx *ctx, float *ms);
 /* Event timing on the context's stream.  mode 0: no events are recorded (nothing but kernels is enqueued);
  * mode 1 (default): one event pair per entry-point call (pysp_ctx_last_kernel_ms); mode 2: in addition each

@@ -40,15 +40,23 @@ def _cpu_share() -> int:
     return max(1, min(n, 16))
 
 
-_TEAM_CACHE = (None, 0)                 # (value of PYSP_HOST_THREADS the size was computed under, size)
+_TEAM_CACHE = (None, 0)                 # (key the size was computed under, size)
+
+
+def _affinity_len() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return -1
 
 
 def team() -> int:
-    """Team size; the affinity mask and the cgroup limit are read once per value of PYSP_HOST_THREADS, not on every call."""
+    """Team size; the cgroup limit is read once per (PYSP_HOST_THREADS, process, width of the affinity mask): a launcher that pins ranks later, or a forked
+    child with a narrower mask, gets its own figure -- the mask width is one cheap system call, the cgroup file is not read again."""
     global _TEAM_CACHE
-    env = os.environ.get("PYSP_HOST_THREADS")
-    if _TEAM_CACHE[1] == 0 or _TEAM_CACHE[0] != env:
-        _TEAM_CACHE = (env, _cpu_share())
+    key = (os.environ.get("PYSP_HOST_THREADS"), os.getpid(), _affinity_len())
+    if _TEAM_CACHE[1] == 0 or _TEAM_CACHE[0] != key:
+        _TEAM_CACHE = (key, _cpu_share())
     return _TEAM_CACHE[1]
 
 

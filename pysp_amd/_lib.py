@@ -43,6 +43,8 @@ _SIGNATURES = {
     "pysp_ctx_set_lab_layout": (_int, [_vp, _int]),
     "pysp_ctx_get_lab_layout": (_int, [_vp]),
     "pysp_ctx_lab_layout_in_use": (_int, [_vp]),
+    "pysp_ctx_set_select_form": (_int, [_vp, _int]),
+    "pysp_ctx_get_select_form": (_int, [_vp]),
     "pysp_ctx_get_lab_lut": (_int, [_vp, _vp]),
     "pysp_ctx_set_stream": (_int, [_vp, _vp]),
     "pysp_ctx_get_stream": (_vp, [_vp]),
@@ -202,6 +204,15 @@ class Context:
         layout = {"auto": -1, "packed": 0, "planes": 1}.get(layout, layout)
         check(lib().pysp_ctx_set_lab_layout(self.handle, int(layout)))
 
+    def set_select_form(self, form) -> None:
+        """Form of the AHD select kernel: 0 / "tile" (one 28x28 px tile per workgroup) or 1 / "stream" (persistent workgroups walking down the columns with
+        carried Lab rows and votes).  Same results either way."""
+        form = {"tile": 0, "stream": 1}.get(form, form)
+        check(lib().pysp_ctx_set_select_form(self.handle, int(form)))
+
+    def get_select_form(self) -> int:
+        return int(lib().pysp_ctx_get_select_form(self.handle))
+
     def get_lab_layout(self) -> int:
         return int(lib().pysp_ctx_get_lab_layout(self.handle))
 
@@ -213,7 +224,8 @@ class Context:
         """The 33^3 grid of lab mode 1 as data: a (33,33,33,3) int16 array ([B][G][R] node, (L, a, b) scaled as OpenCV's RGB2LabLUT_s16) recorded
         from real cv2 by tools/gen_cv2_goldens.py, or None for the built-in restatement."""
         if grid is None:
-            check(lib().pysp_ctx_set_lab_lut(self.handle, None))
+            with self.lock:
+                check(lib().pysp_ctx_set_lab_lut(self.handle, None))
             return
         g = np.ascontiguousarray(grid, dtype=np.int16)
         if g.shape != (33, 33, 33, 3):
@@ -223,7 +235,8 @@ class Context:
 
     def get_lab_lut(self) -> np.ndarray:
         out = np.empty((33, 33, 33, 3), np.int16)
-        check(lib().pysp_ctx_get_lab_lut(self.handle, ctypes.c_void_p(out.ctypes.data)))
+        with self.lock:
+            check(lib().pysp_ctx_get_lab_lut(self.handle, ctypes.c_void_p(out.ctypes.data)))
         return out
 
     def set_stream(self, stream: int) -> None:

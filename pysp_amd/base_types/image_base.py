@@ -60,7 +60,8 @@ class RawDemosaicData:
 
     def is_valid(self) -> bool:
         """Image, coefficients, matrix and exposure value are all present."""
-        have = (self._device_image() is not None or self._img is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
+        # a DeviceArray whose device copy another holder released still resolves through `image` (its host copy): it counts as present (ADVICE r4)
+        have = (self._dev is not None or self._img is not None, self._wb_coeff is not None, self.mat_xyz is not None, self.current_ev != np.inf)
         return all(have)
 
     def _gpu_scale(self, undo: bool):

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -43,6 +44,13 @@ int fail(int code, const char* fmt, ...) {
         if (_r != 0) return fail(PYSP_EHIP, "%s: %s", #expr, hipGetErrorString(hipGetLastError())); \
     } while (0)
 
+// Is `p` page-locked host memory known to the runtime (hipHostMalloc / hipHostRegister)?  Plain pageable memory makes the query fail (or say "unregistered").
+bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 // even, >= 2 and <= 2^20 per side: the kernels form tile-local byte offsets with 24-bit multiplies (row * W * 12 bytes), and no sensor is near that
 bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && H <= (1 << 20) && W <= (1 << 20); }
 
@@ -73,6 +81,12 @@ struct pysp_ctx {
     // (a caller that enqueues hundreds of frames ahead of the GPU sees it late: first version, profiles/r4_ab_lab_layouts_auto_v1_host_runs_ahead.log) -- and
     // back to PACKED if it was clean, or to a HOLD twice as long (at most 4096) if not.
     int lab_layout = -1;
+    // Form of the AHD select kernel (pysp_ctx_set_select_form): 0 one 28x28 px tile per workgroup (k_ahd_select), 1 streaming down the columns with carried Lab
+    // rows and votes (k_ahd_select_stream, round 5; Lab mode 1, packed layout, no HDR metric -- anything else takes the tile form).  Same bits.
+    int select_form = 0;
+    static constexpr int NPLAN = 4;
+    AhdStreamPlan plans[NPLAN];          // chunk queues of the streaming form for the last few frame sizes (a banded host call alternates between two or three)
+    unsigned plan_age[NPLAN] = {}, plan_clock = 0;
     enum { L_PACKED = 0, L_HOLD = 1, L_PROBE = 2, L_WAIT = 3 };
     int layout_state = L_PACKED;
     int layout_now = 0;                  // what the next automatic launch uses: 0 packed, 1 planes
@@ -86,8 +100,8 @@ struct pysp_ctx {
     std::vector<int16_t> lab_grid;   // the 33^3 x 3 grid the device copy was built from (built-in restatement, or injected: pysp_ctx_set_lab_lut)
     Timeline tl;
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_done[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr, up_stream = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_up[2] = {nullptr, nullptr};
     // device buffers handed to callers that keep images on the GPU between calls (pysp_dev_alloc): freed blocks are cached
     struct Block { void* p; size_t cap; bool used; };
     std::vector<Block> blocks;
@@ -229,6 +243,7 @@ int pysp_lab_tables(float* dec, float* cb) {
 }
 
 pysp_ctx* pysp_ctx_create(int device, void* stream) {
+    static const int select_form_env = [] { const char* e = getenv("PYSP_SELECT_FORM"); return e && (e[0] == '0' || !strcmp(e, "tile")) ? 0 : (e && (e[0] == '1' || !strcmp(e, "stream")) ? 1 : -1); }();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) { fail(PYSP_EHIP, "no HIP device available (%s); libpysp_hip has no CPU fallback", hipGetErrorString(e)); return nullptr; }
@@ -237,6 +252,7 @@ pysp_ctx* pysp_ctx_create(int device, void* stream) {
     if ((e = guard.enter(device)) != hipSuccess) { fail(PYSP_EHIP, "hipSetDevice: %s", hipGetErrorString(e)); return nullptr; }
     pysp_ctx* c = new pysp_ctx();
     c->device = device;
+    if (select_form_env >= 0) c->select_form = select_form_env;
     if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
     else {
         if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { fail(PYSP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); delete c; return nullptr; }
@@ -279,7 +295,11 @@ void pysp_ctx_destroy(pysp_ctx* c) {
     for (int i = 0; i < pysp_ctx::NSLOT; i++) if (c->slot[i]) { e = hipFree(c->slot[i]); (void)e; }
     for (auto& b : c->blocks) if (b.p) { e = hipFree(b.p); (void)e; }
     if (c->copy_stream) { e = hipStreamDestroy(c->copy_stream); (void)e; }
+    if (c->up_stream) { e = hipStreamDestroy(c->up_stream); (void)e; }
     for (int i = 0; i < 2; i++) if (c->ev_done[i]) { e = hipEventDestroy(c->ev_done[i]); (void)e; }
+    for (int i = 0; i < 2; i++) if (c->ev_free[i]) { e = hipEventDestroy(c->ev_free[i]); (void)e; }
+    for (int i = 0; i < 2; i++) if (c->ev_up[i]) { e = hipEventDestroy(c->ev_up[i]); (void)e; }
+    for (auto& pl : c->plans) ahd_stream_plan_free(pl);
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
     if (c->labtab) { e = hipFree(c->labtab); (void)e; }
     if (c->lablut) { e = hipFree(c->lablut); (void)e; }
@@ -315,6 +335,13 @@ int pysp_ctx_set_lab_layout(pysp_ctx* ctx, int layout) {
     return PYSP_OK;
 }
 int pysp_ctx_get_lab_layout(pysp_ctx* ctx) { return ctx ? ctx->lab_layout : -2; }
+int pysp_ctx_set_select_form(pysp_ctx* ctx, int form) {
+    CTX_ENTER(ctx);
+    if (form < 0 || form > 1) return fail(PYSP_EBADARG, "select form must be 0 (tiles) or 1 (streaming)");
+    ctx->select_form = form;
+    return PYSP_OK;
+}
+int pysp_ctx_get_select_form(pysp_ctx* ctx) { return ctx ? ctx->select_form : -1; }
 int pysp_ctx_lab_layout_in_use(pysp_ctx* ctx) { return ctx ? (ctx->lab_layout == -1 ? ctx->layout_now : ctx->lab_layout) : -2; }
 
 int pysp_ctx_set_lab_lut(pysp_ctx* ctx, const int16_t* grid) {
@@ -642,26 +669,47 @@ static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, c
                 }
             }
             if (ctx->layout_state == pysp_ctx::L_HOLD && ctx->layout_left == 0) {
-                ctx->layout_state = pysp_ctx::L_PROBE; ctx->layout_left = pysp_ctx::LAYOUT_SAMPLE;
-                HIP_TRY(hipMemcpyAsync(const_cast<unsigned long long*>(ctx->h_layout_count) + 1, ctx->d_layout_count, 8, hipMemcpyDeviceToHost, ctx->stream));   // the probe's baseline
+                // the probe's baseline.  Best effort: a stream that cannot take the copy (e.g. one under graph capture: the destination is read on the
+                // host) must not fail a call whose kernels are fine -- the hold simply goes on and the probe is tried again at the next call
+                if (hipMemcpyAsync(const_cast<unsigned long long*>(ctx->h_layout_count) + 1, ctx->d_layout_count, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess) {
+                    ctx->layout_state = pysp_ctx::L_PROBE; ctx->layout_left = pysp_ctx::LAYOUT_SAMPLE;
+                } else (void)hipGetLastError();
             }
             planes = ctx->layout_state == pysp_ctx::L_HOLD || ctx->layout_state == pysp_ctx::L_WAIT;
             if (!planes) counter = ctx->d_layout_count;
         }
-        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl, planes, counter));
+        // streaming form of the select kernel: the chunk queues of this frame size (built on first use, kept for the last NPLAN sizes)
+        const AhdStreamPlan* plan = nullptr;
+        if (ctx->select_form == 1 && ahd_stream_ok(H, W, hdr != 0, ctx->lab_mode == 1 ? ctx->lablut : nullptr, planes)) {
+            int at = -1, oldest = 0;
+            for (int i = 0; i < pysp_ctx::NPLAN; i++) {
+                if (ctx->plans[i].H == H && ctx->plans[i].W == W && ctx->plans[i].d_chunks) { at = i; break; }
+                if (ctx->plan_age[i] < ctx->plan_age[oldest]) oldest = i;
+            }
+            if (at < 0) { at = oldest; LAUNCH_TRY(ahd_stream_plan_build(ctx->plans[at], H, W, ctx->stream)); }
+            ctx->plan_age[at] = ++ctx->plan_clock;
+            plan = &ctx->plans[at];
+        }
+        LAUNCH_TRY(launch_ahd(ctx->stream, src, H, W, wb, M, hdr != 0, stages, tail, d_out, t0, t1, ctx->labtab, ctx->lab_mode == 1 ? ctx->lablut : nullptr, &ctx->tl, planes, counter, plan));
         if (ctx->lab_mode == 1 && ctx->lab_layout == -1) {
-            bool sample = false;
+            // a sample is ONE 8-byte copy behind the kernels; best effort like the baseline above: when the stream refuses it the state stays where it is
+            // (a probe keeps its last launch open, the periodic sample is retried after the next launch) and the call succeeds -- its output IS produced
+            auto sample = [&]() -> bool {
+                if (hipMemcpyAsync(const_cast<unsigned long long*>(ctx->h_layout_count), ctx->d_layout_count, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess) return true;
+                (void)hipGetLastError();
+                return false;
+            };
             if (counter) {
-                ctx->layout_tiles_enqueued += (unsigned)ahd_select_tiles(H, W);
+                ctx->layout_tiles_enqueued += plan ? plan->passes_total : (unsigned)ahd_select_tiles(H, W);      // what the kernel adds to the device's twin
                 if (ctx->layout_state == pysp_ctx::L_PROBE) {
-                    if (--ctx->layout_left == 0) { sample = true; ctx->layout_probe_target = ctx->layout_tiles_enqueued; ctx->layout_state = pysp_ctx::L_WAIT; }
-                } else if (++ctx->layout_launches % pysp_ctx::LAYOUT_SAMPLE == 0) {
-                    sample = true;
+                    if (ctx->layout_left > 1) ctx->layout_left--;
+                    else if (sample()) { ctx->layout_left = 0; ctx->layout_probe_target = ctx->layout_tiles_enqueued; ctx->layout_state = pysp_ctx::L_WAIT; }
+                } else if (++ctx->layout_launches >= pysp_ctx::LAYOUT_SAMPLE) {
+                    if (sample()) ctx->layout_launches = 0;
                 }
-            } else if (ctx->layout_state == pysp_ctx::L_HOLD) {
+            } else if (ctx->layout_state == pysp_ctx::L_HOLD && ctx->layout_left > 0) {
                 ctx->layout_left--;
             }
-            if (sample) HIP_TRY(hipMemcpyAsync(const_cast<unsigned long long*>(ctx->h_layout_count), ctx->d_layout_count, 8, hipMemcpyDeviceToHost, ctx->stream));
             ctx->layout_now = (ctx->layout_state == pysp_ctx::L_HOLD && ctx->layout_left > 0) || ctx->layout_state == pysp_ctx::L_WAIT;
         }
     } else if (quality == PYSP_QUALITY_FAST) {
@@ -720,7 +768,88 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     }
     if (!ctx->copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
+    }
+    // PYSP_BAND_TRACE=1: host-side clock per band on stderr (where a slow call loses its time)
+    static const bool trace = [] { const char* e = getenv("PYSP_BAND_TRACE"); return e && e[0] == '1'; }();
+    using clk = std::chrono::steady_clock;
+    const auto t_start = clk::now();
+    auto ms_since = [&](clk::time_point t) { return std::chrono::duration<double, std::milli>(t - t_start).count(); };
+    // A page-locked destination (the result blocks of pysp_amd/_hostpool.py, hipHostMalloc) takes truly asynchronous device-to-host copies: the whole band
+    // pipeline is then chained with events from THIS thread -- no helper thread, no host-side hand-over between the bands' downloads (round 5: the helper
+    // thread's wake-ups made this very case bimodal, 5.9 / 7.9 ms at 24 MP, while the pageable destination, whose helper is busy copying, ran at 5.95).
+    // PYSP_HOST_PIPE=thread keeps the helper-thread form for every destination; PYSP_D2H_KERNEL=1 moves a band to the host with a copy kernel instead of a DMA engine.
+    static const int pipe_env = [] { const char* e = getenv("PYSP_HOST_PIPE"); return e && !strcmp(e, "thread") ? 1 : 0; }();
+    static const int h2d_register_env = [] { const char* e = getenv("PYSP_H2D_REGISTER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();     // 1 / 0: always / never page-lock the caller's mosaic for the call
+    static const bool d2h_sync = [] { const char* e = getenv("PYSP_D2H_SYNC"); return e && e[0] == '1'; }();             // experiment: helper thread downloads with the blocking hipMemcpy
+    struct Registered {
+        void* p = nullptr;
+        ~Registered() { if (p) { hipError_t e = hipHostUnregister(p); (void)e; } }
+    } reg;
+    // A page-locked result takes asynchronous downloads; next to those the runtime's blocking upload from PAGEABLE memory either waits for them (event-chained
+    // form: 0.53 ms per band instead of 0.12, 8.7 ms per 24 MP frame) or, issued from a second thread, lands on the downloads' DMA engine every other call
+    // (helper-thread form: 5.8 / 7.0 ms, bimodal -- rounds 2-4's unexplained "pinned result is slower").  So the caller's mosaic is page-locked for the duration
+    // of the call (hipHostRegister: 0.27 ms for 96 MB the first time, measured; the pages are the caller's, nothing is copied) and every transfer of the call is a
+    // plain asynchronous DMA: 5.9 ms, every call (profiles/r5_dropin_probe.log).  A mosaic that cannot be registered (already registered by someone else,
+    // read-only mapping the driver refuses) keeps the helper-thread form.
+    const bool out_pinned = host_is_pinned(out);
+    const bool want_register = h2d_register_env == 1 || (h2d_register_env < 0 && out_pinned && !pipe_env);
+    if (want_register && !host_is_pinned(bayer)) {
+        const auto t0 = clk::now();
+        void* const base = const_cast<T*>(bayer);
+        if (hipHostRegister(base, px * sizeof(T), hipHostRegisterDefault) == hipSuccess) reg.p = base;
+        else {
+            (void)hipGetLastError();
+            if (hipHostRegister(base, px * sizeof(T), hipHostRegisterReadOnly) == hipSuccess) reg.p = base; else (void)hipGetLastError();
+        }
+        if (trace) fprintf(stderr, "[pysp band trace] hipHostRegister %.2f ms (%s)\n", std::chrono::duration<double, std::milli>(clk::now() - t0).count(), reg.p ? "ok" : "failed");
+    }
+    static const bool d2h_kernel = [] { const char* e = getenv("PYSP_D2H_KERNEL"); return e && e[0] == '1'; }();
+    static const int pipe_events = [] { const char* e = getenv("PYSP_HOST_PIPE"); return e && !strcmp(e, "events") ? 1 : 0; }();
+    // (a pageable mosaic keeps the helper-thread form: next to queued asynchronous downloads the runtime's blocking pageable upload takes 0.53 ms per band
+    // instead of 0.12 -- 8.7 ms per frame, profiles/r5_dropin_probe.log -- unless the mosaic was page-locked for the call, PYSP_H2D_REGISTER=1)
+    if (!pipe_env && out_pinned && (pipe_events || reg.p || host_is_pinned(bayer))) {
+        std::vector<double> tr;
+        int rc = PYSP_OK;
+        for (int b = 0; b < nb && rc == PYSP_OK; b++) {
+            const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
+            const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
+            // The upload has a stream of its own.  A copy from PAGEABLE memory is not asynchronous: the runtime first waits, on the host, for everything its
+            // stream holds -- on the kernels' stream that included the wait for band b-2's download (measured: 0.53 ms per band instead of 0.12, 8.6 ms per
+            // 24 MP frame instead of 5.9, profiles/r5_dropin_probe.log).  Here it only waits for the kernels of band b-2, which read d_in[i] and finished long ago.
+            if (b >= 2) HIP_TRY(hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0));
+            if (trace) tr.push_back(ms_since(clk::now()));
+            HIP_TRY(hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->up_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_up[i], ctx->up_stream));
+            if (trace) tr.push_back(ms_since(clk::now()));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[i], 0));
+            if (b >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_free[i], 0));      // d_out[i] may be overwritten once band b-2 has left it (a device-side wait)
+            rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
+            if (rc != PYSP_OK) break;
+            HIP_TRY(hipEventRecord(ctx->ev_done[i], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0));
+            float* const dst = out + (size_t)y0 * W * 3;
+            const float* const src = d_out[i] + (size_t)(y0 - r0) * W * 3;
+            const size_t nbytes = (size_t)(y1 - y0) * W * 12;
+            if (d2h_kernel && launch_copy16(ctx->copy_stream, dst, src, nbytes) == 0) { }
+            else HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_free[i], ctx->copy_stream));
+            if (trace) tr.push_back(ms_since(clk::now()));
+        }
+        // (on an error above the enqueued work still drains below: the buffers belong to the context)
+        hipError_t e = hipStreamSynchronize(ctx->copy_stream);
+        if (trace) {
+            tr.push_back(ms_since(clk::now()));
+            fprintf(stderr, "[pysp band trace, events] %d bands:", nb);
+            for (size_t k = 0; k + 2 < tr.size(); k += 3) fprintf(stderr, " %.2f/%.2f/%.2f", tr[k], tr[k + 1], tr[k + 2]);
+            fprintf(stderr, " | all copied %.2f ms\n", tr.back());
+        }
+        if (rc != PYSP_OK) return rc;
+        if (e != hipSuccess) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(e));
+        return pysp_ctx_sync(ctx);
     }
     // produced[b]: band b's kernels are enqueued and ev_done[b & 1] recorded; consumed: bands whose download has finished
     std::atomic<int> produced{0}, consumed{0}, worker_rc{PYSP_OK}, worker_err{(int)hipSuccess};    // worker_err: the hipError_t the WORKER saw (hipGetLastError is per thread)
@@ -732,19 +861,31 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
             while (produced.load(std::memory_order_acquire) <= b) { if (abort.load()) { consumed = nb; return; } std::this_thread::yield(); }
             const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H, r0 = y0 - halo > 0 ? y0 - halo : 0;
             hipError_t e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0);
+            if (d2h_sync) {
+                e = hipEventSynchronize(ctx->ev_done[i]);
+                if (e == hipSuccess) e = hipMemcpy(out + (size_t)y0 * W * 3, d_out[i] + (size_t)(y0 - r0) * W * 3, (size_t)(y1 - y0) * W * 12, hipMemcpyDeviceToHost);
+            } else {
             if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)y0 * W * 3, d_out[i] + (size_t)(y0 - r0) * W * 3, (size_t)(y1 - y0) * W * 12, hipMemcpyDeviceToHost, ctx->copy_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+            }
             if (e != hipSuccess) { worker_err = (int)e; worker_rc = PYSP_EHIP; }
             consumed.store(b + 1, std::memory_order_release);
         }
     });
     int rc = PYSP_OK;
+    std::vector<double> ttr;
     for (int b = 0; b < nb && rc == PYSP_OK; b++) {
         const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
         const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
-        while (consumed.load(std::memory_order_acquire) < b - 1) std::this_thread::yield();      // buffer i is free again once band b-2 has left it
-        hipError_t e = hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        // upload on its own stream (see the event-chained form above): it waits for the kernels of band b-2 only, not for that band's download
+        hipError_t e = b >= 2 ? hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0) : hipSuccess;
+        if (trace) ttr.push_back(ms_since(clk::now()));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->up_stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_up[i], ctx->up_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_up[i], 0);
+        if (trace) ttr.push_back(ms_since(clk::now()));
         if (e != hipSuccess) { rc = fail(PYSP_EHIP, "hipMemcpyAsync H2D: %s", hipGetErrorString(e)); break; }
+        while (consumed.load(std::memory_order_acquire) < b - 1) std::this_thread::yield();      // d_out[i] is free again once band b-2 has left it
         rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
         if (rc != PYSP_OK) break;
         e = hipEventRecord(ctx->ev_done[i], ctx->stream);
@@ -753,6 +894,11 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     }
     if (rc != PYSP_OK) abort = true;
     worker.join();
+    if (trace) {
+        fprintf(stderr, "[pysp band trace, thread] %d bands (wait-for-buffer / upload issued):", nb);
+        for (size_t k = 0; k + 1 < ttr.size(); k += 2) fprintf(stderr, " %.2f/%.2f", ttr[k], ttr[k + 1]);
+        fprintf(stderr, " | all copied %.2f ms\n", ms_since(clk::now()));
+    }
     if (rc != PYSP_OK) return rc;
     if (worker_rc.load() != PYSP_OK) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString((hipError_t)worker_err.load()));
     return pysp_ctx_sync(ctx);
@@ -916,7 +1062,9 @@ int pysp_fuse_raw_f32(pysp_ctx* ctx, const float* const* frames, int K, int H, i
         }
         if (k0 == 0) ctx->tic();                             // behind the first pass's uploads: one pass (K <= 16) is timed as before, kernel only
         const float* km = K > P ? d_kmax : d_fr[(size_t)kmax];
+        ctx->tl.begin(ctx->stream, "k_fuse_raw");            // one pair per pass (kernel_times() after a host fusion names the kernel again: ADVICE r4)
         LAUNCH_TRY(launch_fuse_raw_pass(ctx->stream, d_fr.data(), n, H, W, ev_off + k0, bias + 4 * k0, k0 == 0, k0 + n == K, km, ev_off[kmax], d_out, d_cnt, part));
+        ctx->tl.end(ctx->stream);
     }
     ctx->toc();
     TRY(d2h(ctx, out, d_out, N * 4));
@@ -946,8 +1094,10 @@ int pysp_fuse_rgb_f32(pysp_ctx* ctx, float* const* frames, int K, size_t npx, co
             d_in[(size_t)k] = d; d_io[(size_t)k] = d;       // in place: each element is read once before it is written
         }
         if (k0 == 0) ctx->tic();
+        ctx->tl.begin(ctx->stream, "k_fuse_rgb");
         LAUNCH_TRY(launch_fuse_rgb_pass(ctx->stream, d_in.data(), write_back ? d_io.data() : nullptr, n, npx, coeff + 3 * k0, applied + k0, ev_off + k0, bias + k0,
                                         k0 == 0, k0 + n == K, (kmax >= k0 && kmax < k0 + n) ? kmax - k0 : -1, ev_off[kmax], M, d_out, d_cnt, part));
+        ctx->tl.end(ctx->stream);
         if (k0 + n == K) ctx->toc();
         if (write_back) for (int k = 0; k < n; k++) TRY(d2h(ctx, frames[k0 + k], d_io[(size_t)k], bytes));      // before the next pass reuses the buffers
     }

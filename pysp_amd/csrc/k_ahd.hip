@@ -21,7 +21,9 @@
 // (round 3: 71 VGPRs, 25.5 KB, six; round 2: 92 VGPRs, 20.6 KB, five).  Template value LAB = 2 keeps round 3's float planes (pysp_ctx_set_lab_layout).
 // -DAHD_TQX / -DAHD_TQY / -DAHD_QPT build the other tile shapes and the two-quads-per-thread form measured in DESIGN.md 7.0 (c).
 // Image-border rules (three of them coexist) are applied at true image edges only.
+#include <stdlib.h>
 #include <type_traits>
+#include <vector>
 
 #include "demosaic_common.h"
 #include "kernels.h"
@@ -998,6 +1000,403 @@ __global__ void __launch_bounds__(NT_A, AHD_MIN_WAVES) k_ahd_select(AhdParams p)
 }
 
 // ================================================================================================
+// Streaming form of kernel A (round 5): a workgroup walks DOWN a column of the image, 16 quad rows per pass, and every one of its 16 thread rows produces
+// an output row.  The stand-alone tile above spends two of its 16 thread rows on halo (Lab and votes of the rows above and below its 14 output rows are
+// computed again by the neighbouring tiles: 12.5 % of every phase); here the rows above come from the previous pass of the SAME workgroup:
+//   * Lab of the last two pixel rows of a pass (both directions) and the votes of its pixel rows 29 and 30 are carried in LDS;
+//   * the vote of a pixel needs the Lab row below it and the selection of a quad row the votes of the pixel row below it, so the bottom quad row of a pass
+//     cannot be selected in that pass: its two candidates wait in an LDS stash (owned by the very threads that computed them) and are selected one pass later,
+//     by the same threads -- thread row 15 selects the stashed row, thread rows 0..14 their own: 16 output rows per pass.
+// Votes are computed for the pixel rows -1..30 of the pass (-1 = the last row of the previous pass), i.e. a vote thread takes the pixel pair one row ABOVE
+// its CFA quad (the vote does not care about the CFA), from the Lab buffer rows 2 lqy .. 2 lqy + 3 as before: the buffer simply holds rows -2..31 now.
+// A column is cut into CHUNKS (head pass: 14 rows, like a tile; every further pass: 16) which the workgroups of a persistent grid fetch from per-XCD
+// queues (an XCD owns a contiguous range of columns: neighbours share their halo columns through its L2); the chunks get shorter towards the end of a queue
+// (guided self-scheduling, api.cpp) so that the grid drains evenly.  Same arithmetic, pixel for pixel, as k_ahd_select: the parity tests run both.
+// Lab mode 1, packed cells, no HDR metric (the instances the benchmark and BASELINE configs 2 and 5 use); everything else keeps the tile kernel.
+namespace {
+constexpr int S_CARRY_CELLS = 2 * 32;                       // two Lab pixel rows x 32 cells (px 0..31 of the region) per direction
+struct StreamLds {
+    static constexpr int NMW = 4 * MWY * MWX, NGQ = 4 * GY * GXS, NLAB = 2 * LPR * LPS;
+    static constexpr int NCARRY = 2 * S_CARRY_CELLS * 2;    // floats: [dir][row][cell]{L, ab}
+    static constexpr int NCV = 2 * MPS / 2;                 // floats: two vote rows of MPS uint16
+    static constexpr int NSTASH = 22 * TQX;                 // floats: 22 candidate values of the TQX quads of thread row 15
+    static constexpr int N = NMW + NGQ + NLAB + 2 + NCARRY + NCV + NSTASH;
+};
+constexpr int SMPR = 2 * LQY + 2;                           // vote map rows of the streaming form: pixel rows -3..30 of the pass
+static_assert(SMPR * MPS * sizeof(unsigned short) <= StreamLds::NMW * sizeof(float), "the vote map fits over the mosaic planes");
+
+// Rows [R0, R1) of the 4x4 window of cells for the streaming form: window row r = pixel row 2 lqy - 2 + r of the pass; the thread votes for the pixels of rows 1 and 2.
+// BORDER_REFLECT (ahd.py:64) duplicates the image's edge rows: vt_top -- row 1 lies above the image (its own votes are never consumed), row 2 is the image's first
+// row and sees itself there; vt_bot -- row 2 lies below the image, row 1 is the last row.
+template <int R0, int R1>
+DEVI void load_labrows_pk_s(const float* lab, int lqy, int lqx, bool vt_top, bool vt_bot, bool at_left, bool at_right, float wl[4][4], unsigned wc[4][4]) {
+    const float4* p = reinterpret_cast<const float4*>(lab) + (2 * lqy) * LC4 + lqx;
+#pragma unroll
+    for (int r = R0; r < R1; r++) {
+        const float4 a = p[r * LC4], b = p[r * LC4 + 1];
+        wl[r][0] = a.x; wc[r][0] = __float_as_uint(a.y); wl[r][1] = a.z; wc[r][1] = __float_as_uint(a.w);
+        wl[r][2] = b.x; wc[r][2] = __float_as_uint(b.y); wl[r][3] = b.z; wc[r][3] = __float_as_uint(b.w);
+    }
+    if (vt_top | vt_bot | at_left | at_right) {   // interior waves skip the selects
+#pragma unroll
+        for (int r = R0; r < R1; r++) {
+            if (at_left) { wl[r][0] = wl[r][1]; wc[r][0] = wc[r][1]; }
+            if (at_right) { wl[r][3] = wl[r][2]; wc[r][3] = wc[r][2]; }
+        }
+        if (R0 == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (vt_top) { wl[1][c] = wl[2][c]; wc[1][c] = wc[2][c]; }
+                if (vt_bot) { wl[2][c] = wl[1][c]; wc[2][c] = wc[1][c]; }
+            }
+        }
+    }
+}
+
+// One pass: region = quad rows Q0 .. Q0 + 15 of column tile tbx.  `chained`: the pass above was run by this workgroup just before (carry and stash are valid).
+// Output: quad rows Q0 (chained) or Q0 + 1 (head) .. Q0 + 14, and the stashed row Q0 - 1 (chained), none below E (the chunk's last row).
+template <bool U16, bool TAIL>
+DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, const int E, float* const planes, int* const s_flag) {
+    constexpr int NMW = StreamLds::NMW, NGQ = StreamLds::NGQ, NLAB = StreamLds::NLAB;
+    int tbx = tbx_in;
+    asm volatile("" : "+s"(tbx));                        // (what follows from the column is derived afresh in every pass as well)
+    // The kernel's arguments are read from the argument segment again in every pass (scalar loads through a pointer the compiler cannot see through): loaded once
+    // in front of the pass loop they all stay in scalar registers across it -- the colour matrix, pointers and sizes of every phase at once, on top of the loop's
+    // state and the per-lane flag masks: more than the 102 scalar registers, and the spills go to vector register lanes (the one-pass build: 87 SGPRs, no spills).
+    // AhdParams is the kernel's FIRST argument: offset 0 of the segment.
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    typedef __attribute__((address_space(4))) const AhdParams KArgs;
+    KArgs* const pa = (KArgs*)ka;
+    AhdParams p;
+    p.src.f32 = pa->src.f32; p.src.u16 = pa->src.u16;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { p.src.black[i] = pa->src.black[i]; p.src.sat[i] = pa->src.sat[i]; p.src.rsat[i] = pa->src.rsat[i]; }
+    p.out = pa->out; p.labtab = nullptr; p.lablut = pa->lablut; p.H = pa->H; p.W = pa->W; p.hdr = 0; p.tail = pa->tail; p.float_form_tiles = pa->float_form_tiles;
+#pragma unroll
+    for (int i = 0; i < 3; i++) p.wb[i] = pa->wb[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) p.ccm.m[i] = pa->ccm.m[i];
+    float* const mw = planes;
+    float* const gq = planes + NMW;
+    float* const lab = planes + NMW + NGQ;
+    float* const carry_lab = lab + NLAB + 2;                                         // [dir][2 * 32 cells][2]
+    unsigned* const carry_vote = reinterpret_cast<unsigned*>(carry_lab + StreamLds::NCARRY);   // two vote rows, MPS uint16 each
+    float* const stash = carry_lab + StreamLds::NCARRY + StreamLds::NCV;              // [22][TQX]
+    unsigned short* const vmap = reinterpret_cast<unsigned short*>(planes);           // [SMPR][MPS] votes h | v << 8 (row m = pixel row m - 3), over the dead mosaic planes
+
+    // opaque per pass: everything derived from the thread index (LDS addresses, offsets, flags) is recomputed in every pass instead of being hoisted out of
+    // the pass loop and kept in registers across it (hoisted: 127 VGPRs; the kernel needs <= 80 for six waves per SIMD)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
+    const int tq0x = tbx * TQX, tq0y = Q0 + 1;           // (the tile kernel's coordinates: its region starts one quad row above its tile)
+    const double* M = p.ccm.m;
+    const bool inside = tq0y >= 3 && tq0x >= 3 && tq0y + TQY + 3 <= h && tq0x + TQX + 3 <= w;
+    __syncthreads();                                     // the previous pass is done with the vote map (over the mosaic planes)
+    if (tid == 0) s_flag[2] = 0;
+
+    // ---- P0: as in ahd_select_tile
+    {
+        static_assert(MWX <= 32 && NT_A % 32 == 0, "a pair row fits in 32 lanes");
+        constexpr int RPP = NT_A / 32, NROWS = 2 * MWY, NL = (NROWS + RPP - 1) / RPP;
+        const int r = tid >> 5, c = tid & 31;
+        const bool on = c < MWX;
+        const int cc = on ? c : MWX - 1;
+        const int dy = r & 1;
+        static_assert(RPP % 2 == 0, "row parity is a per-lane constant");
+        float2 tmp[NL];
+        if (!U16 && inside) {
+            const char* const tile = reinterpret_cast<const char*>(p.src.f32 + (size_t)(2 * (tq0y - 3)) * W + 2 * (tq0x - 3));
+            const unsigned rowb = (unsigned)W * 4u;
+            const unsigned voff = mul24((unsigned)r, rowb) + 8u * (unsigned)cc;
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const int ry = (NROWS % RPP == 0 || r + k * RPP < NROWS) ? k * RPP : 0;
+                tmp[k] = *reinterpret_cast<const float2*>(tile + (voff + (unsigned)ry * rowb));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const int ry = min(r + k * RPP, NROWS - 1), my = ry >> 1;
+                int qi = tq0y - 3 + my, qj = tq0x - 3 + cc;
+                if (!inside) { qi = b_sym1(qi, h); qj = b_sym1(qj, w); }
+                tmp[k] = load_mosaic_pair<U16>(p.src, (size_t)(2 * qi + dy) * W + 2 * qj, dy != 0);
+            }
+        }
+        const float w0 = dy ? p.wb[1] : p.wb[0], w1 = dy ? p.wb[2] : p.wb[1];
+        float* const d0 = mw + ((dy ? P_G2 : P_R) * MWY + (r >> 1)) * MWX + cc;
+        float* const d1 = mw + ((dy ? P_B : P_G1) * MWY + (r >> 1)) * MWX + cc;
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (on && (NROWS % RPP == 0 || r + k * RPP < NROWS)) {
+                d0[k * (RPP / 2) * MWX] = tmp[k].x * w0;
+                d1[k * (RPP / 2) * MWX] = tmp[k].y * w1;
+            }
+    }
+    __syncthreads();
+
+#define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
+    auto green_planes = [&](const int dir) {
+        for (int idx = tid; idx < GY * GX; idx += NT_A) {
+            int gy = idx / GX, gx = idx - gy * GX;
+            int a = gy + 1, c = gx + 1;
+            if (!inside) {
+                int ri = b_1011(tq0y - 2 + gy, h);
+                int rj = b_1011(tq0x - 2 + gx, w);
+                a = ri - (tq0y - 3); c = rj - (tq0x - 3);
+                if (a < 1 || a > MWY - 2 || c < 1 || c > MWX - 2) continue;
+            }
+            const float rc = MWAT(P_R, a, c), bc = MWAT(P_B, a, c);
+            float gr, gb;
+            if (dir == 0) {
+                gr = (((MWAT(P_R, a, c - 1) * AH0 + MWAT(P_G1, a, c - 1) * AH1) + rc * AH2) + MWAT(P_G1, a, c) * AH1) + MWAT(P_R, a, c + 1) * AH0;
+                gb = (((MWAT(P_B, a, c - 1) * AH0 + MWAT(P_G2, a, c) * AH1) + bc * AH2) + MWAT(P_G2, a, c + 1) * AH1) + MWAT(P_B, a, c + 1) * AH0;
+            } else {
+                gr = (((MWAT(P_R, a - 1, c) * AH0 + MWAT(P_G2, a - 1, c) * AH1) + rc * AH2) + MWAT(P_G2, a, c) * AH1) + MWAT(P_R, a + 1, c) * AH0;
+                gb = (((MWAT(P_B, a - 1, c) * AH0 + MWAT(P_G1, a, c) * AH1) + bc * AH2) + MWAT(P_G1, a + 1, c) * AH1) + MWAT(P_B, a + 1, c) * AH0;
+            }
+            const int gi = gy * GXS + gx;
+            gq[0 * GY * GXS + gi] = gr; gq[1 * GY * GXS + gi] = gb;
+            gq[2 * GY * GXS + gi] = rc - gr; gq[3 * GY * GXS + gi] = bc - gb;
+        }
+    };
+    green_planes(0);
+    __syncthreads();
+
+    // This thread's quad: region row lqy = quad row Q0 + lqy, region column lqx = quad column tq0x - 1 + lqx.  The coordinates and the per-lane flags (scalar
+    // register pairs) are derived afresh in every phase from an opaque copy of the thread index: kept across the phases, the flags of all of them together with
+    // the pass loop's state exceed the scalar registers, and the spills go to vector register lanes (86 VGPRs; the kernel needs <= 80 for six waves per SIMD)
+    auto fresh = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+
+    float rgbh[4][3], rgbv[4][3];
+    unsigned hvotes = 0;
+#pragma unroll
+    for (int dir = 0; dir < 2; dir++) {
+        // the two Lab pixel rows above the region, from the previous pass (wave 0: one cell per lane)
+        if (chained && tid < S_CARRY_CELLS) {
+            const float2 cell = reinterpret_cast<const float2*>(carry_lab)[dir * S_CARRY_CELLS + tid];
+            reinterpret_cast<float2*>(lab)[(tid >> 5) * LPS + 1 + (tid & 31)] = cell;
+        }
+        float rr[4], gg[4], bb[4];
+        const int t2 = fresh();
+        const int lqy = t2 / LQX, lqx = t2 - lqy * LQX;
+        const int qi = Q0 + lqy, qj = tq0x - 1 + lqx;
+        const int gy = lqy + 1, gx = lqx + 1, my = lqy + 2, mx = lqx + 2;
+        if (qi >= 0 && qi < h && qj >= 0 && qj < w) {
+            const bool at_top = qi == 0, at_bot = qi == h - 1, at_left = qj == 0, at_right = qj == w - 1;
+            const float* gR = gq, *gB = gq + GY * GXS, *dR = gq + 2 * GY * GXS, *dB = gq + 3 * GY * GXS;
+            Win3 wgr = load_win<GXS>(gR, gy, gx), wgb = load_win<GXS>(gB, gy, gx);
+            const float g1_c = dir == 0 ? MWAT(P_G1, my, mx) : rgbh[1][1], g2_c = dir == 0 ? MWAT(P_G2, my, mx) : rgbh[2][1];
+            float Wn[4][4] = {{wgb.v[0][0], MWAT(P_G2, my - 1, mx), wgb.v[0][1], MWAT(P_G2, my - 1, mx + 1)},
+                              {MWAT(P_G1, my, mx - 1), wgr.v[1][1], g1_c, wgr.v[1][2]},
+                              {wgb.v[1][0], g2_c, wgb.v[1][1], MWAT(P_G2, my, mx + 1)},
+                              {MWAT(P_G1, my + 1, mx - 1), wgr.v[2][1], MWAT(P_G1, my + 1, mx), wgr.v[2][2]}};
+            if (at_top | at_bot | at_left | at_right) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (at_top) Wn[0][k] = Wn[2][k];
+                    if (at_bot) Wn[3][k] = Wn[1][k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (at_left) Wn[k][0] = Wn[k][2];
+                    if (at_right) Wn[k][3] = Wn[k][1];
+                }
+            }
+            float hf[4];
+            highpass_quad(Wn, hf);
+            float fg[4], fd[4];
+            filt_base_tl(wgr, fg);
+            { Win3 wd = load_win<GXS>(dR, gy, gx); filt_base_tl(wd, fd); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) rr[k] = fd[k] + (fg[k] + hf[k]);
+            filt_base_br(wgb, fg);
+            { Win3 wd = load_win<GXS>(dB, gy, gx); filt_base_br(wd, fd); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) bb[k] = fd[k] + (fg[k] + hf[k]);
+            gg[0] = wgr.v[1][1]; gg[1] = g1_c; gg[2] = g2_c; gg[3] = wgb.v[1][1];
+            float (&rgbc)[4][3] = dir == 0 ? rgbh : rgbv;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float L; unsigned ab;
+                homog_lab_pk(p.lablut, rr[k], gg[k], bb[k], p.wb, M, 0, L, ab);
+                // pixel (py, px) of the region lives at buffer row py + 2 (rows 0, 1: carried), column px + 1
+                float2* const o = reinterpret_cast<float2*>(lab) + (2 * lqy + 2 + (k >> 1)) * LPS + 2 * lqx + 1 + (k & 1);
+                *o = make_float2(L, __uint_as_float(ab));
+                rgbc[k][0] = rr[k]; rgbc[k][1] = gg[k]; rgbc[k][2] = bb[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+
+        // ---- P3: votes of the pixel pair rows (2 lqy - 1, 2 lqy) of the region, from buffer rows 2 lqy .. 2 lqy + 3: the vote thread's pixel pair lies one
+        // pixel row above its quad, image rows 2 qi - 1 (upper) and 2 qi (lower)
+        if (qj >= 0 && qj < w && qi >= 0 && qi <= h) {
+            const bool vt_top = qi == 0, vt_bot = qi == h, at_left = qj == 0, at_right = qj == w - 1;
+            int cnt[4];
+            unsigned long long big;
+            {
+                float wl[4][4]; unsigned wc[4][4], ec[4], pc[6];
+                load_labrows_pk_s<0, 3>(lab, lqy, lqx, vt_top, vt_bot, at_left, at_right, wl, wc);
+                if (dir == 0) { vote_eps_pk<0, 0, 2>(wc, ec, pc); vote_cells_pk<0, 0, 2>(wl, wc, ec, pc, cnt); }
+                else { vote_eps_pk<1, 0, 2>(wc, ec, pc); vote_cells_pk<1, 0, 2>(wl, wc, ec, pc, cnt); }
+                const unsigned long long big0 = __builtin_amdgcn_ballot_w64(ec[0] >= (1u << 24)), big1 = __builtin_amdgcn_ballot_w64(ec[1] >= (1u << 24));
+                __builtin_amdgcn_sched_barrier(0);
+                load_labrows_pk_s<3, 4>(lab, lqy, lqx, vt_top, vt_bot, at_left, at_right, wl, wc);
+                if (dir == 0) { vote_eps_pk<0, 2, 4>(wc, ec, pc); vote_cells_pk<0, 2, 4>(wl, wc, ec, pc, cnt); }
+                else { vote_eps_pk<1, 2, 4>(wc, ec, pc); vote_cells_pk<1, 2, 4>(wl, wc, ec, pc, cnt); }
+                // only votes that are consumed may raise the flag (see the tile kernel): image pixels whose window holds real Lab values
+                const bool vote_rows_ok = chained || lqy >= 1;                       // a head pass has no Lab above its region
+                const unsigned long long rowU = __builtin_amdgcn_ballot_w64(vote_rows_ok && qi >= 1), rowL = __builtin_amdgcn_ballot_w64(vote_rows_ok && qi < h);
+                const unsigned long long colL = __builtin_amdgcn_ballot_w64(lqx >= 1), colR = __builtin_amdgcn_ballot_w64(lqx <= TQX);
+                big = (big0 & rowU & colL) | (big1 & rowU & colR) |
+                      (__builtin_amdgcn_ballot_w64(ec[2] >= (1u << 24)) & rowL & colL) | (__builtin_amdgcn_ballot_w64(ec[3] >= (1u << 24)) & rowL & colR);
+            }
+            if (big != 0) {
+                s_flag[2] = 1;
+                asm volatile("" ::: "memory");
+                float wl[4][4]; unsigned wc[4][4];
+                load_labrows_pk_s<0, 3>(lab, lqy, lqx, vt_top, vt_bot, at_left, at_right, wl, wc);
+                unsigned pk = dir == 0 ? vote_quad_pk_f32<0, 0, 2>(wl, wc) : vote_quad_pk_f32<1, 0, 2>(wl, wc);
+                __builtin_amdgcn_sched_barrier(0);
+                load_labrows_pk_s<3, 4>(lab, lqy, lqx, vt_top, vt_bot, at_left, at_right, wl, wc);
+                pk |= dir == 0 ? vote_quad_pk_f32<0, 2, 4>(wl, wc) : vote_quad_pk_f32<1, 2, 4>(wl, wc);
+#pragma unroll
+                for (int k = 0; k < 4; k++) cnt[k] = (int)((pk >> (4 * k)) & 15u);
+            }
+            if (dir == 0) {
+                hvotes = (unsigned)cnt[0] | ((unsigned)cnt[1] << 4) | ((unsigned)cnt[2] << 8) | ((unsigned)cnt[3] << 12);
+            } else {
+                // vote map row m = pixel row m - 3 of the region: this thread's pixel rows 2 lqy - 1, 2 lqy -> m = 2 lqy + 2, 2 lqy + 3; column = px + 1 - 2 (tile origin - 1 px)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int yy = 2 * lqy + 2 + (k >> 1), xx = 2 * lqx - 1 + (k & 1);
+                    if (xx >= 0 && xx < 2 * TQX + 2)
+                        vmap[yy * MPS + xx] = (unsigned short)(((hvotes >> (4 * k)) & 15u) | ((unsigned)cnt[k] << 8));
+                }
+            }
+        }
+        // the last two Lab pixel rows of this direction (buffer rows 32, 33) travel to the next pass (wave 3: one cell per lane)
+        if (tid >= NT_A - S_CARRY_CELLS) {
+            const int j = tid - (NT_A - S_CARRY_CELLS);
+            reinterpret_cast<float2*>(carry_lab)[dir * S_CARRY_CELLS + j] = reinterpret_cast<const float2*>(lab)[(2 * LQY + (j >> 5)) * LPS + 1 + (j & 31)];
+        }
+        if (dir == 0) {
+            green_planes(1);
+            __syncthreads();
+        } else if (chained && tid < MPS) {
+            reinterpret_cast<unsigned*>(vmap)[tid] = carry_vote[tid];      // vote rows m = 0, 1 (pixel rows -3, -2): the previous pass's rows 29, 30
+        }
+    }
+#undef MWAT
+    __syncthreads();
+    if (tid == 0 && p.float_form_tiles != nullptr && s_flag[2] != 0) atomicAdd(p.float_form_tiles, 1u);
+
+    // ---- P4: thread rows 0..14 select their own quad row, thread row 15 the row stashed by the previous pass (quad row Q0 - 1); then the stash takes row 15's candidates
+    const int t4 = fresh();
+    const int lqy = t4 / LQX, lqx = t4 - lqy * LQX;
+    const int qi = Q0 + lqy, qj = tq0x - 1 + lqx;
+    const bool active = qi >= 0 && qi < h && qj >= 0 && qj < w;
+    const bool at_left = qj == 0, at_right = qj == w - 1;
+    const bool last_row = lqy == LQY - 1;
+    const bool col_ok = lqx >= 1 && lqx <= TQX && qj < w;
+    bool sel;
+    int orow;                                                                        // output quad row relative to Q0 - 1
+    if (last_row) {
+        sel = chained && col_ok;                                                     // (a chunk continues only while rows remain: Q0 - 1 <= E)
+        orow = 0;
+        if (col_ok) {
+            // swap: the stash's candidates into the registers, this pass's into the stash (thread-private slots: no barrier)
+            float* const sp = stash + (lqx - 1);
+            int n = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    { const float old = sp[n * TQX]; sp[n * TQX] = rgbh[k][c]; rgbh[k][c] = old; n++; }
+                    if (!(c == 1 && (k == 1 || k == 2))) { const float old = sp[n * TQX]; sp[n * TQX] = rgbv[k][c]; rgbv[k][c] = old; n++; }
+                    else rgbv[k][c] = rgbh[k][c];                                   // the quad's own two green samples are the same in both candidates
+                }
+        }
+    } else {
+        sel = active && col_ok && (chained || lqy >= 1) && qi <= E;
+        orow = lqy + 1;
+    }
+    if (sel) {
+        const int sqi = Q0 - 1 + orow;                                               // the selected quad row in the image
+        const bool s_top = sqi == 0, s_bot = sqi == h - 1;
+        const int m0 = 2 * orow;                                                     // vote rows m0 .. m0 + 3 = pixel rows 2 sqi - 1 .. 2 sqi + 2
+        const int vmx = 2 * lqx - 1;
+        unsigned int s012[4], s123[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned int* wp = reinterpret_cast<const unsigned int*>(&vmap[(m0 + r) * MPS + vmx - 1]);
+            uint2 wv = make_uint2(wp[0], wp[1]);
+            if (at_left) wv.x = (wv.x & 0xFFFF0000u) | (wv.y & 0xFFFFu);
+            if (at_right) wv.y = (wv.y & 0xFFFFu) | (wv.x & 0xFFFF0000u);
+            unsigned int a = wv.x & 0xFFFFu, b = wv.x >> 16, cc = wv.y & 0xFFFFu, d = wv.y >> 16;
+            s012[r] = a + b + cc; s123[r] = b + cc + d;
+        }
+        if (s_top) { s012[0] = s012[2]; s123[0] = s123[2]; }
+        if (s_bot) { s012[3] = s012[1]; s123[3] = s123[1]; }
+        float px[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int dy = k >> 1, dx = k & 1;
+            unsigned int sm = dx ? (s123[dy] + s123[dy + 1] + s123[dy + 2]) : (s012[dy] + s012[dy + 1] + s012[dy + 2]);
+            unsigned int sh = sm & 0xFFu, sv = sm >> 8;
+            float cf = sh < sv ? 1.0f : 0.0f, nc = 1.0f - cf;
+            px[k][0] = rgbh[k][0] * cf + rgbv[k][0] * nc;
+            px[k][1] = rgbh[k][1] * cf + rgbv[k][1] * nc;
+            px[k][2] = rgbh[k][2] * cf + rgbv[k][2] * nc;
+            if (TAIL) colour_tail(p.tail, M, px[k][0], px[k][1], px[k][2]);
+        }
+        // origin = quad (Q0 - 1, tq0x) of the image (Q0 - 1 >= 0 whenever row 0 of this origin is stored: chained passes only)
+        char* const origin = reinterpret_cast<char*>(p.out) + ((long long)(2 * (Q0 - 1)) * W + 2 * tq0x) * 12;
+        store_quad_direct(reinterpret_cast<float*>(origin), W, orow, lqx - 1, px);
+    }
+    // the votes of pixel rows 29, 30 (rows m = 32, 33) for the next pass
+    if (tid < MPS) carry_vote[tid] = reinterpret_cast<const unsigned*>(vmap)[(SMPR - 2) * (MPS / 2) + tid];
+}
+}  // namespace
+
+struct AhdStreamQueues {
+    const int4* chunks;          // [0..3]: header -- first[8] then count[8]: XCD x owns chunks[4 + first[x] .. 4 + first[x] + count[x]); then one entry per chunk:
+                                 // { column tile, S = region origin quad row of the head pass, E = last output quad row, passes }
+    unsigned passes_total;       // of the whole launch (the layout policy's "tiles launched")
+};
+#ifndef STREAM_MIN_WAVES
+#define STREAM_MIN_WAVES 1
+#endif
+template <bool U16, bool TAIL>
+__global__ void __launch_bounds__(NT_A, STREAM_MIN_WAVES) k_ahd_select_stream(AhdParams p, AhdStreamQueues q) {
+    __shared__ __attribute__((aligned(16))) float planes[StreamLds::N];
+    __shared__ int s_flag[4];
+    const unsigned xcd = blockIdx.x & 7u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.float_form_tiles != nullptr) atomicAdd(p.float_form_tiles + 1, q.passes_total);
+    {
+        // one workgroup per chunk, dispatched by the hardware in queue order (the j-th workgroup of XCD x takes the j-th chunk of queue x): no fetch, no exit protocol
+        const unsigned* const hdr = reinterpret_cast<const unsigned*>(q.chunks);
+        const unsigned idx = blockIdx.x >> 3;
+        if (idx >= hdr[8 + xcd]) return;
+        const int4 chv = q.chunks[4 + hdr[xcd] + idx];
+        const int4 ch = make_int4(__builtin_amdgcn_readfirstlane(chv.x), __builtin_amdgcn_readfirstlane(chv.y), __builtin_amdgcn_readfirstlane(chv.z), __builtin_amdgcn_readfirstlane(chv.w));
+        int Q0 = ch.y;
+        bool chained = false;
+#ifdef STREAM_ONEPASS      // (register-pressure probe only)
+        ahd_stream_pass<U16, TAIL>(ch.x, Q0, ch.w != 0, ch.z, planes, s_flag);
+#else
+        for (;;) {
+            ahd_stream_pass<U16, TAIL>(ch.x, Q0, chained, ch.z, planes, s_flag);
+            if (Q0 + LQY - 1 > ch.z) break;
+            Q0 += LQY; chained = true;
+        }
+#endif
+    }
+}
+
+// ================================================================================================
 // Kernel B: one chroma post-process stage (ahd.py:148-161) + optional colour tail.
 //   r' = med5(r-g)+g ; b' = med5(b-g)+g ; g' = (med5(g-r') + med5(g-b') + r' + b') / 2
 // cv2.medianBlur(.,5): exact 5x5 median, BORDER_REPLICATE.
@@ -1360,9 +1759,74 @@ __global__ void __launch_bounds__(NT_A, 1) k_ahd_fused(AhdParams a, MedParams m,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Chunk queues of the streaming select kernel for one frame size.  XCD x owns a contiguous range of column tiles; its columns are cut, top to bottom, into
+// chunks of 14 + 16 m quad rows (a head pass and m chained passes, m <= 7); m follows the work that is left in the queue (guided self-scheduling: the rows left
+// divided by twice the queue's workgroups), so the first chunks are long (15.7 output rows per pass) and the last ones single passes that fill the grid's drain.
+int ahd_stream_plan_build(AhdStreamPlan& plan, int H, int W, hipStream_t st) {
+    if (plan.H == H && plan.W == W && plan.d_chunks) return 0;
+    static int cus = 0, occ = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ahd_select_stream<false, false>, NT_A, 0) != hipSuccess || occ <= 0) occ = 6;
+        (void)hipGetLastError();
+    }
+    const int h = H / 2, w = W / 2, ncols = (w + TQX - 1) / TQX;
+    std::vector<int4> chunks(4);                                    // header: first[8], count[8]
+    unsigned passes = 0;
+    unsigned grid = (unsigned)(cus * occ) & ~7u;
+    // experiment switches (tools/ab_stream.sh): longest chunk 14 + 16 m rows, grid size, divisor of the guided schedule
+    static const int env_maxm = [] { const char* e = getenv("PYSP_STREAM_MAXM"); return e ? atoi(e) : 7; }();
+    static const int env_grid = [] { const char* e = getenv("PYSP_STREAM_GRID"); return e ? atoi(e) : 0; }();
+    static const int env_div = [] { const char* e = getenv("PYSP_STREAM_DIV"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
+    if (env_grid > 0) grid = (unsigned)env_grid & ~7u;
+    if (grid < 8) grid = 8;
+    const long long slots = grid / 8;
+    for (int x = 0; x < 8; x++) {
+        const int c0 = (int)((long long)ncols * x / 8), c1 = (int)((long long)ncols * (x + 1) / 8);
+        plan.first[x] = (unsigned)chunks.size() - 4u;
+        long long left = (long long)(c1 - c0) * h;
+        for (int c = c0; c < c1; c++) {
+            int r = 0;
+            while (r < h) {
+                long long want = left / (env_div * slots);
+                int m = want <= TQY ? 0 : (int)((want - TQY) / LQY);
+                if (m > env_maxm) m = env_maxm;
+                int len = TQY + LQY * m;
+                if (r + len > h || h - (r + len) < 3) len = h - r;               // (no sliver of one or two rows at the bottom of a column)
+                int np = 1;
+                for (int q0 = r - 1; q0 + LQY - 1 <= r + len - 1; q0 += LQY) np++;   // the kernel's own loop
+                chunks.push_back(make_int4(c, r - 1, r + len - 1, np));
+                passes += (unsigned)np;
+                r += len; left -= len;
+            }
+        }
+        plan.count[x] = (unsigned)chunks.size() - 4u - plan.first[x];
+    }
+    for (int x = 0; x < 8; x++) { reinterpret_cast<unsigned*>(chunks.data())[x] = plan.first[x]; reinterpret_cast<unsigned*>(chunks.data())[8 + x] = plan.count[x]; }
+    // (an earlier launch may still read the old table)
+    if (hipStreamSynchronize(st) != hipSuccess) return -3;
+    if (plan.d_chunks) { (void)hipFree(plan.d_chunks); plan.d_chunks = nullptr; }
+    if (hipMalloc(&plan.d_chunks, chunks.size() * sizeof(int4)) != hipSuccess) return -3;
+    if (hipMemcpy(plan.d_chunks, chunks.data(), chunks.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess) return -3;
+    unsigned longest = 0;
+    for (int x = 0; x < 8; x++) longest = plan.count[x] > longest ? plan.count[x] : longest;
+    plan.grid = 8u * longest;                                       // workgroup 8 j + x takes chunk j of queue x (or leaves at once if the queue is shorter)
+    plan.passes_total = passes; plan.n_chunks = (unsigned)chunks.size() - 4u;
+    plan.H = H; plan.W = W;
+    return 0;
+}
+void ahd_stream_plan_free(AhdStreamPlan& plan) {
+    if (plan.d_chunks) { (void)hipFree(plan.d_chunks); plan.d_chunks = nullptr; }
+    plan.H = plan.W = 0;
+}
+bool ahd_stream_ok(int H, int W, int hdr, const void* d_lablut, int lab_planes) {
+    return d_lablut != nullptr && !lab_planes && !hdr && H / 2 >= 4 && W / 2 >= 4;
+}
+
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut, Timeline* tl, int lab_planes,
-               unsigned* d_float_form_tiles) {
+               unsigned* d_float_form_tiles, const AhdStreamPlan* stream_plan) {
     AhdParams a;
     a.float_form_tiles = d_float_form_tiles;
     a.labtab = reinterpret_cast<const float4*>(d_labtab);
@@ -1386,7 +1850,14 @@ int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
         else hipLaunchKernelGGL((k_ahd_select<false, false, HDRV, LABV, TAILV>), ga, dim3(NT_A), 0, st, a); \
     } while (0)
 #define AHD_LAUNCH(HDRV, LABV) do { if (a.tail != 0) AHD_LAUNCH2(HDRV, LABV, true); else AHD_LAUNCH2(HDRV, LABV, false); } while (0)
-    if (d_lablut && lab_planes) { if (hdr) AHD_LAUNCH(true, 2); else AHD_LAUNCH(false, 2); }
+    if (stream_plan && stream_plan->H == H && stream_plan->W == W && ahd_stream_ok(H, W, hdr, d_lablut, lab_planes)) {
+        AhdStreamQueues q;
+        q.chunks = reinterpret_cast<const int4*>(stream_plan->d_chunks); q.passes_total = stream_plan->passes_total;
+        const dim3 gs(stream_plan->grid);
+        if (u16) { if (a.tail != 0) hipLaunchKernelGGL((k_ahd_select_stream<true, true>), gs, dim3(NT_A), 0, st, a, q); else hipLaunchKernelGGL((k_ahd_select_stream<true, false>), gs, dim3(NT_A), 0, st, a, q); }
+        else { if (a.tail != 0) hipLaunchKernelGGL((k_ahd_select_stream<false, true>), gs, dim3(NT_A), 0, st, a, q); else hipLaunchKernelGGL((k_ahd_select_stream<false, false>), gs, dim3(NT_A), 0, st, a, q); }
+    }
+    else if (d_lablut && lab_planes) { if (hdr) AHD_LAUNCH(true, 2); else AHD_LAUNCH(false, 2); }
     else if (d_lablut) { if (hdr) AHD_LAUNCH(true, 1); else AHD_LAUNCH(false, 1); }
     else { if (hdr) AHD_LAUNCH(true, 0); else AHD_LAUNCH(false, 0); }
 #undef AHD_LAUNCH2

@@ -263,3 +263,19 @@ int launch_gamma(hipStream_t st, const float* in, size_t n, int decode, float* o
     hipLaunchKernelGGL(k_gamma_flat, dim3(grid), dim3(256), 0, st, in, n, decode, out);
     return CHECK_LAUNCH();
 }
+
+// Device -> page-locked host memory by a kernel instead of a DMA engine (api.cpp, banded host pipeline, PYSP_D2H_KERNEL=1): `dst` is the device-visible address of
+// a hipHostMalloc block, written with 16-byte stores over PCIe.  n16 = number of 16-byte pieces.
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += stride) dst[q] = src[q];
+}
+int launch_copy16(hipStream_t st, void* dst, const void* src, size_t bytes) {
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) || (bytes & 15)) return -1;
+    const size_t n16 = bytes / 16;
+    unsigned grid = (unsigned)((n16 + 255) / 256);
+    if (grid > 512) grid = 512;              // a few waves per CU are enough to keep the link busy; the compute kernels of the next band share the chip
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+    return CHECK_LAUNCH();
+}

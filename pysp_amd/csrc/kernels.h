@@ -32,13 +32,24 @@ int launch_cam_to_rgb(hipStream_t st, const float* in, size_t npx, const double 
 int launch_gamma(hipStream_t st, const float* in, size_t n, int decode, float* out);
 int launch_wb_scale(hipStream_t st, const float* in, size_t npx, const float coeff[3], int undo, float* out);
 int launch_colour_tail(hipStream_t st, const float* in, size_t npx, const double M[9], int tail, float* out);
+int launch_copy16(hipStream_t st, void* dst, const void* src, size_t bytes);   // 16-byte aligned device -> mapped host (or device) copy by a kernel
 
+// Streaming form of the select kernel (round 5, k_ahd.hip): the chunk queues of one frame size, device resident; api.cpp keeps a few per context.
+struct AhdStreamPlan {
+    int H = 0, W = 0;
+    void* d_chunks = nullptr;         // int4 { column tile, head pass origin, last output quad row, passes } per chunk
+    unsigned first[8] = {}, count[8] = {}, passes_total = 0, n_chunks = 0, grid = 0;
+};
+int ahd_stream_plan_build(AhdStreamPlan& plan, int H, int W, hipStream_t st);   // builds and uploads unless the plan already is for (H, W); may synchronise st
+void ahd_stream_plan_free(AhdStreamPlan& plan);
+bool ahd_stream_ok(int H, int W, int hdr, const void* d_lablut, int lab_planes);
 // k_ahd.hip: tail = colour tail of devmath.h (0 none, 1 lin sRGB, 2 sRGB, 3 Reinhard + sRGB);
 // d_tmp0/d_tmp1 are (H,W,3) scratch images (only needed when stages >= 1 / >= 2).
 int launch_ahd(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int hdr, int stages,
                int tail, float* d_out, float* d_tmp0, float* d_tmp1, const float* d_labtab, const void* d_lablut /* Lab mode 1, else NULL */,
                Timeline* tl = nullptr, int lab_planes = 0 /* Lab mode 1: float Lab planes and float votes (round 3's form) instead of packed cells */,
-               unsigned* d_float_form_tiles = nullptr /* packed form: device counter, +1 per tile in which a wave redid its votes in float arithmetic */);
+               unsigned* d_float_form_tiles = nullptr /* packed form: device counter, +1 per tile in which a wave redid its votes in float arithmetic */,
+               const AhdStreamPlan* stream_plan = nullptr /* non-NULL and eligible (ahd_stream_ok): the streaming form of the select kernel */);
 int ahd_select_tiles(int H, int W);   // workgroups of one k_ahd_select launch
 
 // A batch of n frames through AHD with one median stage (Lab mode 1): n + 1 launches, select tiles of frame i + 1 and median tiles of frame i sharing one grid

@@ -195,7 +195,11 @@ def test_no_kernel_uses_scratch_or_spills(tmp_path):
     assert len(kernels) >= 30
     bad = {k: v for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
-    hot = {k: v for k, v in kernels.items() if "k_ahd_select" in k or "k_ahd_median_stage" in k}
+    stream = {k: v for k, v in kernels.items() if "k_ahd_select_stream" in k}
+    assert len(stream) == 4                                          # the streaming form of the select kernel (round 5): uint16 x colour tail; SIX workgroups per CU
+    for k, v in stream.items():
+        assert v["vgpr_count"] <= 80 and v["group_segment_fixed_size"] <= 163840 // 6, (k, v)
+    hot = {k: v for k, v in kernels.items() if ("k_ahd_select" in k and k not in stream) or "k_ahd_median_stage" in k}
     assert len(hot) == 49                                            # 48 select variants (tiny / uint16 / HDR metric / Lab form 0, 1, 2 / colour tail) and the median stage
     for k, v in hot.items():
         if "k_ahd_median_stage" in k:                                # five 256-thread workgroups per CU: <= 96 VGPRs and <= 32 KB of LDS
