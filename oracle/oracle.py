@@ -435,14 +435,16 @@ def flat_field(bayer, flat, clamp_high: bool = False) -> np.ndarray:
     return out
 
 
-def warp_table(kr0, kr1, kr2, kr3, kt0, kt1, width, height, cxn, cyn, scale, seed=None) -> np.ndarray:
-    out = np.empty((height, width, 2), np.float32)
+def warp_table(kr0, kr1, kr2, kr3, kt0, kt1, width, height, cxn, cyn, scale, seed=None, rows=None) -> np.ndarray:
+    """dng_warp_rectilinear_coords.pyx:18-96; rows=(y0, y1): only those rows of the table (a band of a frame too large to tabulate whole)."""
+    y0, y1 = (0, int(height)) if rows is None else (int(rows[0]), int(rows[1]))
+    out = np.empty((y1 - y0, width, 2), np.float32)
     sp = None
     if seed is not None:
         seed = _f32(seed); sp = _p(seed)
     f = ctypes.c_float
-    _chk(lib().orc_warp_table(f(kr0), f(kr1), f(kr2), f(kr3), f(kt0), f(kt1), int(width), int(height), f(cxn), f(cyn),
-                              f(scale), sp, _p(out)), "warp_table")
+    _chk(lib().orc_warp_table_rows(f(kr0), f(kr1), f(kr2), f(kr3), f(kt0), f(kt1), int(width), int(height), f(cxn), f(cyn),
+                                   f(scale), sp, y0, y1, _p(out)), "warp_table")
     return out
 
 
@@ -452,10 +454,12 @@ def lanczos4_table() -> np.ndarray:
 
 
 def remap_lanczos4(src, mapx, mapy) -> np.ndarray:
+    """Restated cv2.remap(INTER_LANCZOS4): the result has the maps' shape (any shape: e.g. a band of rows of a larger warp); the source is the whole plane."""
     s, mx, my = map(_f32, (src, mapx, mapy))
     H, W = s.shape
-    out = np.empty_like(s)
-    _chk(lib().orc_remap_lanczos4(_p(s), H, W, _p(mx), _p(my), _p(out)), "remap")
+    assert mx.shape == my.shape
+    out = np.empty(mx.shape, np.float32)
+    _chk(lib().orc_remap_lanczos4_n(_p(s), H, W, _p(mx), _p(my), ctypes.c_size_t(mx.size), _p(out)), "remap")
     return out
 
 

@@ -988,19 +988,24 @@ static inline void warp_px(float sx, float sy, float kr0, float kr1, float kr2, 
     *ox = sx + (xp - sx) * scale;
     *oy = sy + (yp - sy) * scale;
 }
-int orc_warp_table(float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
-                   float cxn, float cyn, float scale, const float *seed /* NULL or (H,W,2) */, float *table) {
-    if (width <= 0 || height <= 0) return ORC_EBADARG;
+/* rows [y0, y1) of the table only (table: (y1-y0, W, 2); seed, when given, is the whole (H,W,2) prior): a band of a frame too large to tabulate whole */
+int orc_warp_table_rows(float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
+                        float cxn, float cyn, float scale, const float *seed /* NULL or (H,W,2) */, int y0, int y1, float *table) {
+    if (width <= 0 || height <= 0 || y0 < 0 || y1 > height || y0 > y1) return ORC_EBADARG;
     float cx, cy, m;
     warp_setup(width, height, cxn, cyn, &cx, &cy, &m);
 #pragma omp parallel for
-    for (int y = 0; y < height; y++)
+    for (int y = y0; y < y1; y++)
         for (int x = 0; x < width; x++) {
-            size_t o = ((size_t)y * width + x) * 2;
+            size_t o = ((size_t)y * width + x) * 2, t = ((size_t)(y - y0) * width + x) * 2;
             float sx = seed ? seed[o] : (float)x, sy = seed ? seed[o + 1] : (float)y;
-            warp_px(sx, sy, kr0, kr1, kr2, kr3, kt0, kt1, m, cx, cy, scale, &table[o], &table[o + 1]);
+            warp_px(sx, sy, kr0, kr1, kr2, kr3, kt0, kt1, m, cx, cy, scale, &table[t], &table[t + 1]);
         }
     return ORC_OK;
+}
+int orc_warp_table(float kr0, float kr1, float kr2, float kr3, float kt0, float kt1, int width, int height,
+                   float cxn, float cyn, float scale, const float *seed /* NULL or (H,W,2) */, float *table) {
+    return orc_warp_table_rows(kr0, kr1, kr2, kr3, kt0, kt1, width, height, cxn, cyn, scale, seed, 0, height, table);
 }
 
 /* Restated cv2.remap(plane, mapx, mapy, INTER_LANCZOS4) float32, BORDER_CONSTANT 0
@@ -1027,13 +1032,16 @@ static void lanczos4_tab(float tab[32][8]) {
     }
 }
 int orc_lanczos4_table(float *tab256) { lanczos4_tab((float(*)[8])tab256); return ORC_OK; }
+/* n output pixels with their own maps (any shape: a band of rows of a larger warp); the source is always the whole (H,W) plane */
+int orc_remap_lanczos4_n(const float *src, int H, int W, const float *mapx, const float *mapy, size_t n, float *dst);
 int orc_remap_lanczos4(const float *src, int H, int W, const float *mapx, const float *mapy, float *dst) {
+    return orc_remap_lanczos4_n(src, H, W, mapx, mapy, (size_t)H * W, dst);
+}
+int orc_remap_lanczos4_n(const float *src, int H, int W, const float *mapx, const float *mapy, size_t n, float *dst) {
     float tab[32][8];
     lanczos4_tab(tab);
 #pragma omp parallel for
-    for (int y = 0; y < H; y++)
-        for (int x = 0; x < W; x++) {
-            size_t o = (size_t)y * W + x;
+    for (size_t o = 0; o < n; o++) {
             int sx = (int)lrintf(mapx[o] * 32.0f), sy = (int)lrintf(mapy[o] * 32.0f);
             int ix = (sx >> 5) - 3, iy = (sy >> 5) - 3;
             const float *wx = tab[sx & 31], *wy = tab[sy & 31];

@@ -954,6 +954,19 @@ int pysp_pipeline_batch_dev(pysp_ctx* ctx, const float* const* d_bayers, int n_f
         ctx->toc();
         return PYSP_OK;
     }
+    // Draft / EAG (BASELINE config 3: eight EAG frames per rank and step): the frames of a batch share ONE grid, blockIdx.z = frame (round 5) -- no launch
+    // boundary, no drain and fill between frames of 0.09 ms each.  PYSP_BATCH_GRID=0 keeps the frame-by-frame launches (A/B).
+    static const bool batch_grid = [] { const char* e = getenv("PYSP_BATCH_GRID"); return !(e && e[0] == '0'); }();
+    if (batch_grid && n_frames >= 2 && (quality == PYSP_QUALITY_FAST || quality == PYSP_QUALITY_DRAFT) && wb && even_dims(H, W) && H / 2 >= 4 && W / 2 >= 4 && (M || !tail)) {
+        for (int i = 0; i < n_frames; i++)
+            if (!d_bayers[i] || !d_outs[i]) return fail(PYSP_EBADARG, "pipeline_batch: null frame pointer");
+        ctx->tic();
+        const void* const* srcs = reinterpret_cast<const void* const*>(d_bayers);
+        if (quality == PYSP_QUALITY_FAST) LAUNCH_TRY(launch_eag_batch(ctx->stream, srcs, 0, nullptr, nullptr, n_frames, H, W, wb, M, tail, d_outs, &ctx->tl));
+        else LAUNCH_TRY(launch_draft_batch(ctx->stream, srcs, 0, nullptr, nullptr, n_frames, H, W, wb, M, tail, d_outs, &ctx->tl));
+        ctx->toc();
+        return PYSP_OK;
+    }
     for (int i = 0; i < n_frames; i++) TRY(run_pipeline_dev(ctx, d_bayers[i], H, W, wb, M, quality, hdr, stages, tail, d_outs[i]));
     return PYSP_OK;
 }

@@ -27,6 +27,26 @@ DEVI void xcd_tile(int& bx, int& by) {
 #endif
 }
 
+// The same for a batch of frames in one grid (blockIdx.z = frame, gridDim.x x gridDim.y tiles each).  The hardware numbers the workgroups of the whole grid
+// (z-major) and deals THAT number round-robin to the XCDs, so a frame whose tile count is no multiple of 8 starts on another XCD than the one before it: the
+// map takes the workgroup's real XCD, g & 7 with g its number in the grid, and gives XCD k the k-th contiguous run of the frame's tiles -- as many tiles as
+// the frame has workgroups on that XCD.
+DEVI void xcd_tile_batch(int& bx, int& by) {
+    const unsigned gx = gridDim.x, n = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned g0 = blockIdx.z * n, g = g0 + lin, k = g & 7u;
+    // workgroups of this frame on XCD c: the numbers g0 <= g' < g0 + n with g' & 7 == c; first_c = g0 + ((c - g0) & 7)
+    const unsigned first = g0 + ((k - g0) & 7u), j = (g - first) >> 3;
+    unsigned start = 0;
+#pragma unroll
+    for (unsigned c = 0; c < 7; c++) {
+        const unsigned off = (c - g0) & 7u;                          // offset of XCD c's first workgroup inside the frame
+        const unsigned cnt = off < n ? (n - off + 7u) >> 3 : 0u;
+        start += c < k ? cnt : 0u;
+    }
+    const unsigned t = start + j;
+    by = (int)(t / gx); bx = (int)(t - (unsigned)by * gx);
+}
+
 // The same, with the XCD's share walked in vertical strips of SW tiles: a kernel whose tiles overlap their upper / lower neighbours by many rows (the
 // Lanczos warp: 11 of 27 source rows) finds those rows in its L2 only if the neighbour ran a moment ago -- a full tile row of a 100 MP frame is as large
 // as the L2 itself.  Within a strip tiles run row-major, strips left to right; the last strip takes whatever width is left.

@@ -84,6 +84,8 @@ DEVI void mosaic_commit(float (*mw)[MWY][MWX], const float4 tmp[NL4], int tid) {
         }
     }
 }
+constexpr int FRAME_BATCH_MAX = 16;
+struct FrameBatch { const void* src[FRAME_BATCH_MAX]; float* out[FRAME_BATCH_MAX]; };      // frames of one launch of k_eag_batch / k_draft_batch
 struct EagParams {
     MosaicSrc src;
     float* out;
@@ -95,7 +97,7 @@ struct EagParams {
 
 // TAIL is a template parameter: with the colour tail chosen at run time the kernel needs 66 VGPRs, with it fixed 40 (8 waves/SIMD)
 template <bool TINY, bool U16, int TAIL>
-__global__ void __launch_bounds__(NT) k_eag(EagParams p) {
+DEVI void eag_tile(const EagParams& p, const int tbx, const int tby) {
     // one LDS block: the raw planes and the green / difference planes first, then (after a barrier) the finished RGB tile,
     // which leaves the workgroup as whole 16-byte stores (stage_tile_store)
     constexpr int NPLANES = 4 * MWY * MWX + 4 * GY * GX, NSTAGE = (2 * TQY) * (2 * TQX * 3);
@@ -105,8 +107,6 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     static_assert((4 * MWY * MWX) % 2 == 0, "8-byte aligned pairs");
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const bool inside = tq0y >= 2 && tq0x >= 2 && tq0y + TQY + 2 <= h && tq0x + TQX + 2 <= w;   // no border rule applies in P0/P1
     // P0: raw planes, cv2.copyMakeBorder(..., BORDER_REFLECT) per plane (eag.py:86-87).
@@ -211,6 +211,24 @@ __global__ void __launch_bounds__(NT) k_eag(EagParams p) {
     }
     if (staged) stage_tile_store<2 * TQX, 2 * TQY, NT>(lds, p.out, W, 2 * tq0y, 2 * tq0x, lqy, lqx, px);
 }
+template <bool TINY, bool U16, int TAIL>
+__global__ void __launch_bounds__(NT) k_eag(EagParams p) {
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    eag_tile<TINY, U16, TAIL>(p, tbx, tby);
+}
+// A batch of frames of one size in ONE grid (blockIdx.z = frame; BASELINE config 3: eag of 8 frames per rank and step): no launch boundary and no
+// drain / fill between the frames of a batch.  The frames' pointers travel in the kernel arguments.
+template <bool U16, int TAIL>
+__global__ void __launch_bounds__(NT) k_eag_batch(EagParams p, FrameBatch b) {
+    int tbx, tby;
+    xcd_tile_batch(tbx, tby);
+    const unsigned z = blockIdx.z;
+    if (U16) p.src.u16 = reinterpret_cast<const uint16_t*>(b.src[z]); else p.src.f32 = reinterpret_cast<const float*>(b.src[z]);
+    p.out = b.out[z];
+    eag_tile<false, U16, TAIL>(p, tbx, tby);
+}
+
 
 int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
     EagParams a;
@@ -239,6 +257,29 @@ int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float w
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// Frames of one size, float32 or uint16 mosaics, in grids of up to FRAME_BATCH_MAX frames (quarter planes of at least 4 x 4: the caller checks)
+int launch_eag_batch(hipStream_t st, const void* const* d_srcs, int u16, const float black[4], const float sat[4], int n, int H, int W, const float wb[3], const double M[9],
+                     int tail, float* const* d_outs, Timeline* tl) {
+    if (n <= 0 || H / 2 < 4 || W / 2 < 4 || tail < 0 || tail > 3) return -1;
+    EagParams a;
+    a.src = u16 ? mosaic_u16(nullptr, black, sat) : mosaic_f32(nullptr);
+    a.out = nullptr; a.H = H; a.W = W; a.tail = tail;
+    for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
+    for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
+    for (int f0 = 0; f0 < n; f0 += FRAME_BATCH_MAX) {
+        const int nb = n - f0 < FRAME_BATCH_MAX ? n - f0 : FRAME_BATCH_MAX;
+        FrameBatch b = {};
+        for (int i = 0; i < nb; i++) { b.src[i] = d_srcs[f0 + i]; b.out[i] = d_outs[f0 + i]; }
+        const dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY, nb);
+        if (tl) tl->begin(st, "k_eag");
+#define EAGB(T) do { if (u16) hipLaunchKernelGGL((k_eag_batch<true, T>), g, dim3(NT), 0, st, a, b); else hipLaunchKernelGGL((k_eag_batch<false, T>), g, dim3(NT), 0, st, a, b); } while (0)
+        switch (tail) { case 0: EAGB(0); break; case 1: EAGB(1); break; case 2: EAGB(2); break; default: EAGB(3); break; }
+#undef EAGB
+        if (tl) tl->end(st);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // ================================================================================================
 // Draft (fast_resize.py:21-39): quarter-resolution RGB with 3/4-1/4 diagonal R/B alignment, then
 // bilinear x2 (half-pixel centres, edge clamp; horizontal pass then vertical pass).
@@ -262,15 +303,13 @@ constexpr int DQX = TQX + 2, DQY = TQY + 2;     // q planes, halo 1 quad
 }  // namespace
 
 template <bool TINY, bool U16, int TAIL>
-__global__ void __launch_bounds__(NT) k_draft(EagParams p) {
+DEVI void draft_tile(const EagParams& p, const int tbx, const int tby) {
     constexpr int NPLANES = 4 * MWY * MWX + 3 * DQY * DQX, NSTAGE = (2 * TQY) * (2 * TQX * 3);
     __shared__ __attribute__((aligned(16))) float lds[NPLANES > NSTAGE ? NPLANES : NSTAGE];
     float (*mw)[MWY][MWX] = reinterpret_cast<float (*)[MWY][MWX]>(lds);
     float (*q)[DQY][DQX] = reinterpret_cast<float (*)[DQY][DQX]>(lds + 4 * MWY * MWX);
     const int tid = threadIdx.x;
     const int H = p.H, W = p.W, h = H >> 1, w = W >> 1;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
     const int tq0x = tbx * TQX, tq0y = tby * TQY;
     const bool inside = tq0y >= 2 && tq0x >= 2 && tq0y + TQY + 2 <= h && tq0x + TQX + 2 <= w;   // no clamp applies anywhere in the tile
     {
@@ -334,6 +373,24 @@ __global__ void __launch_bounds__(NT) k_draft(EagParams p) {
     }
     if (staged) stage_tile_store<2 * TQX, 2 * TQY, NT>(lds, p.out, W, 2 * tq0y, 2 * tq0x, lqy, lqx, px);
 }
+template <bool TINY, bool U16, int TAIL>
+__global__ void __launch_bounds__(NT) k_draft(EagParams p) {
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    draft_tile<TINY, U16, TAIL>(p, tbx, tby);
+}
+// A batch of frames of one size in ONE grid (blockIdx.z = frame; BASELINE config 3: draft of 8 frames per rank and step): no launch boundary and no
+// drain / fill between the frames of a batch.  The frames' pointers travel in the kernel arguments.
+template <bool U16, int TAIL>
+__global__ void __launch_bounds__(NT) k_draft_batch(EagParams p, FrameBatch b) {
+    int tbx, tby;
+    xcd_tile_batch(tbx, tby);
+    const unsigned z = blockIdx.z;
+    if (U16) p.src.u16 = reinterpret_cast<const uint16_t*>(b.src[z]); else p.src.f32 = reinterpret_cast<const float*>(b.src[z]);
+    p.out = b.out[z];
+    draft_tile<false, U16, TAIL>(p, tbx, tby);
+}
+
 
 int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl) {
     EagParams a;
@@ -359,6 +416,28 @@ int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float
     }
 #undef DRAFT_LAUNCH
     if (tl) tl->end(st);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_draft_batch(hipStream_t st, const void* const* d_srcs, int u16, const float black[4], const float sat[4], int n, int H, int W, const float wb[3], const double M[9],
+                       int tail, float* const* d_outs, Timeline* tl) {
+    if (n <= 0 || H / 2 < 4 || W / 2 < 4 || tail < 0 || tail > 3) return -1;
+    EagParams a;
+    a.src = u16 ? mosaic_u16(nullptr, black, sat) : mosaic_f32(nullptr);
+    a.out = nullptr; a.H = H; a.W = W; a.tail = tail;
+    for (int i = 0; i < 3; i++) a.wb[i] = wb[i];
+    for (int i = 0; i < 9; i++) a.ccm.m[i] = M ? M[i] : (i % 4 == 0 ? 1.0 : 0.0);
+    for (int f0 = 0; f0 < n; f0 += FRAME_BATCH_MAX) {
+        const int nb = n - f0 < FRAME_BATCH_MAX ? n - f0 : FRAME_BATCH_MAX;
+        FrameBatch b = {};
+        for (int i = 0; i < nb; i++) { b.src[i] = d_srcs[f0 + i]; b.out[i] = d_outs[f0 + i]; }
+        const dim3 g((W / 2 + TQX - 1) / TQX, (H / 2 + TQY - 1) / TQY, nb);
+        if (tl) tl->begin(st, "k_draft");
+#define DRAFTB(T) do { if (u16) hipLaunchKernelGGL((k_draft_batch<true, T>), g, dim3(NT), 0, st, a, b); else hipLaunchKernelGGL((k_draft_batch<false, T>), g, dim3(NT), 0, st, a, b); } while (0)
+        switch (tail) { case 0: DRAFTB(0); break; case 1: DRAFTB(1); break; case 2: DRAFTB(2); break; default: DRAFTB(3); break; }
+#undef DRAFTB
+        if (tl) tl->end(st);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -61,6 +61,12 @@ int launch_ahd_pipelined(hipStream_t st, const MosaicSrc* srcs, int n, int H, in
 // k_eag.hip
 int launch_eag(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
 int launch_draft(hipStream_t st, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int tail, float* d_out, Timeline* tl = nullptr);
+// n frames of one size in ONE grid per 16 frames (blockIdx.z = frame): float32 mosaics (u16 = 0) or raw uint16 ones with their black / saturation levels; frames of at
+// least 8 x 8 px (the caller falls back to n single launches otherwise); returns -1 on a bad argument
+int launch_eag_batch(hipStream_t st, const void* const* d_srcs, int u16, const float black[4], const float sat[4], int n, int H, int W, const float wb[3], const double M[9],
+                     int tail, float* const* d_outs, Timeline* tl = nullptr);
+int launch_draft_batch(hipStream_t st, const void* const* d_srcs, int u16, const float black[4], const float sat[4], int n, int H, int W, const float wb[3], const double M[9],
+                       int tail, float* const* d_outs, Timeline* tl = nullptr);
 
 int launch_resample_g(hipStream_t st, const float* g1, const float* g2, int h, int w, int weighted, float* out);
 int launch_highpass(hipStream_t st, const float* g, int H, int W, float* out);

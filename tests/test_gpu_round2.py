@@ -310,7 +310,17 @@ def test_bench_default_line_contract():
     assert line["metric"].startswith("megapixels/sec AHD debayer+cam->sRGB") and line["unit"] == "MP/s" and line["dtype"] == "f32"
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["vs_baseline"] is None
     r = line["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"]
+    # round 5: `bound` names what binds -- the VALU issue rate of the two AHD kernels -- next to the contract's HBM figures (frac = hbm_frac); issue_bound carries
+    # the class mix of the built library (profiles/isa_mix.json), the executed instruction counts (PMC) and the [lo, hi] bracket of the cost model
+    assert r["bound"] == "valu_issue" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] and r["hbm_frac"] == r["frac"]
+    ib = r["issue_bound"]
+    assert ib["kernel"] == r["kernel"] and set(ib["class_counts_static"]) == set("FABT") and ib["class_counts_static"]["B"] > 100
+    lo, hi = ib["frac_of_issue_bound"]
+    assert 0.5 < lo <= hi < 1.35, ib["frac_of_issue_bound"]             # the kernel runs where its instruction mix says it should (DESIGN.md 7.R4 a)
+    slo, shi = ib["step_frac_of_issue_bound"]
+    assert 0.5 < slo <= shi < 1.35 and slo > 5 * r["frac"]               # ... an order of magnitude closer to that bound than to the HBM roofline
+    assert ib["stale"] in (False, True) and set(ib["all_kernels"]) == {"k_ahd_select", "k_ahd_median_stage"}
+    assert line["config"]["streams_per_rank"] == 2 and line["config"]["per_kernel_sampling"].startswith("one stream")
     # round 4: frac is the STEP's fraction (16 B per output pixel over the step time); the dominant kernel's own figure sits under its own key
     assert abs(r["achieved"] - 16 * 24e6 / (line["ms_per_step"] * 1e-3) / 1e9) < 0.5 and r["frac"] == r["pipeline_frac"]
     dk = r["dominant_kernel"]

@@ -2,15 +2,16 @@
 # Copies the artefacts of the last `tools/collect_profiles.sh <tag>` call (gpurun_out/<tag>_final/) into profiles/ under the round's names and regenerates
 # profiles/traffic.json:   bash tools/adopt_collection.sh r3
 set -e
-tag=${1:-r4}
+tag=${1:-r5}
 F=gpurun_out/${tag}_final
 cp $F/bench.json profiles/${tag}_bench.json
 cp $F/bench_driver_20_5.json profiles/${tag}_bench_driver_20_5.json
 cp $F/kernel_stats.csv profiles/${tag}_kernel_stats.csv
 cp $F/workloads.jsonl profiles/${tag}_workloads.jsonl
 for k in ahd24 eag24ccm draft12 warp100; do cp $F/pmc_${k}_summary.csv profiles/${tag}_pmc_${k}_summary.csv; cp $F/pmc_${k}_lib.sha256 profiles/${tag}_pmc_${k}_lib.sha256; done
-for f in dropin_time config_time native_units_gpu ubench_valu ubench_pairs ubench_stream gputest; do [ -f $F/$f.log ] && cp $F/$f.log profiles/${tag}_$f.log; done
+for f in dropin_time dropin_probe config_time native_units_gpu ubench_valu ubench_pairs ubench_stream gputest; do [ -f $F/$f.log ] && cp $F/$f.log profiles/${tag}_$f.log; done
 python3 tools/make_traffic.py $tag > /dev/null
+python3 tools/make_isa_mix.py > /dev/null
 python3 - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]

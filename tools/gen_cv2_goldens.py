@@ -157,6 +157,19 @@ def record_reference(cv2, ref_path):
         print("wrote cv2_" + name)
 
 
+def write_calls(cv2, out_dir):
+    """Record the nine calls with the module `cv2` (the real one, or a stand-in with the same entry points: tests/test_cv2_goldens.py dry-runs the ingest with
+    oracle/cv2_restated.py) into out_dir/cv2_calls.npz; returns the path."""
+    out = record_calls(cv2)
+    build = cv2.getBuildInformation() if hasattr(cv2, "getBuildInformation") else ""
+    ipp = [l.strip() for l in build.splitlines() if "IPP" in l][:3]
+    feats = cv2.getCPUFeaturesLine() if hasattr(cv2, "getCPUFeaturesLine") else ""
+    out["meta"] = np.array(json.dumps({"cv2": getattr(cv2, "__version__", "?"), "numpy": np.__version__, "ipp": ipp, "cpu_features": feats}))
+    path = os.path.join(out_dir, "cv2_calls.npz")
+    np.savez_compressed(path, **out)
+    return path, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=None, help="path of a pySP checkout: also record its full demosaic with the real cv2")
@@ -170,11 +183,7 @@ def main():
         sys.exit(f"cv2 {cv2.__version__} found, the reference pins 4.10.0.84 (pass --any-version to record anyway)")
     cv2.setNumThreads(1)
     cv2.ocl.setUseOpenCL(False)
-    out = record_calls(cv2)
-    build = cv2.getBuildInformation()
-    ipp = [l.strip() for l in build.splitlines() if "IPP" in l][:3]
-    out["meta"] = np.array(json.dumps({"cv2": cv2.__version__, "numpy": np.__version__, "ipp": ipp, "cpu_features": cv2.getCPUFeaturesLine()}))
-    np.savez_compressed(os.path.join(GOLDEN, "cv2_calls.npz"), **out)
+    _path, out = write_calls(cv2, GOLDEN)
     print("wrote tests/golden/cv2_calls.npz:", {k: v.shape for k, v in out.items() if k != "meta"})
     if args.reference:
         record_reference(cv2, args.reference)
