@@ -1053,6 +1053,16 @@ DEVI void load_labrows_pk_s(const float* lab, int lqy, int lqx, bool vt_top, boo
     }
 }
 
+// Diagnostic build only (-DAHD_STAMPS): the stamps of the streaming form ACCUMULATE per wave -- slot i holds the sum over the wave's passes of (clock at boundary i -
+// clock at the pass's first stamp), slot 15 the number of passes -- so that differences of neighbouring slots divided by the count are mean cycles per pass and phase.
+#ifdef AHD_STAMPS
+#define SSTAMP(i) do { if ((threadIdx.x & 63) == 0) { \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((i) == 0) st_t0 = t_; \
+        const unsigned wv_ = blockIdx.x * (NT_A / 64) + (threadIdx.x >> 6); \
+        if (wv_ < (unsigned)AHD_STAMP_WAVES) { g_ahd_stamps[(size_t)wv_ * AHD_NSTAMP + (i)] += t_ - st_t0; if ((i) == 13) g_ahd_stamps[(size_t)wv_ * AHD_NSTAMP + 15] += 1ull; } } } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
 // One pass: region = quad rows Q0 .. Q0 + 15 of column tile tbx.  `chained`: the pass above was run by this workgroup just before (carry and stash are valid).
 // Output: quad rows Q0 (chained) or Q0 + 1 (head) .. Q0 + 14, and the stashed row Q0 - 1 (chained), none below E (the chunk's last row).
 template <bool U16, bool TAIL>
@@ -1093,6 +1103,8 @@ DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, co
     const int tq0x = tbx * TQX, tq0y = Q0 + 1;           // (the tile kernel's coordinates: its region starts one quad row above its tile)
     const double* M = p.ccm.m;
     const bool inside = tq0y >= 3 && tq0x >= 3 && tq0y + TQY + 3 <= h && tq0x + TQX + 3 <= w;
+    unsigned long long st_t0 = 0; (void)st_t0;
+    SSTAMP(0);
     __syncthreads();                                     // the previous pass is done with the vote map (over the mosaic planes)
     if (tid == 0) s_flag[2] = 0;
 
@@ -1134,7 +1146,9 @@ DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, co
                 d1[k * (RPP / 2) * MWX] = tmp[k].y * w1;
             }
     }
+    SSTAMP(1);
     __syncthreads();
+    SSTAMP(2);
 
 #define MWAT(pl, yy, xx) mw[((pl) * MWY + (yy)) * MWX + (xx)]
     auto green_planes = [&](const int dir) {
@@ -1162,7 +1176,9 @@ DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, co
         }
     };
     green_planes(0);
+    SSTAMP(3);
     __syncthreads();
+    SSTAMP(4);
 
     // This thread's quad: region row lqy = quad row Q0 + lqy, region column lqx = quad column tq0x - 1 + lqx.  The coordinates and the per-lane flags (scalar
     // register pairs) are derived afresh in every phase from an opaque copy of the thread index: kept across the phases, the flags of all of them together with
@@ -1228,7 +1244,9 @@ DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, co
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        SSTAMP(dir == 0 ? 5 : 9);
         __syncthreads();
+        SSTAMP(dir == 0 ? 6 : 10);
 
         // ---- P3: votes of the pixel pair rows (2 lqy - 1, 2 lqy) of the region, from buffer rows 2 lqy .. 2 lqy + 3: the vote thread's pixel pair lies one
         // pixel row above its quad, image rows 2 qi - 1 (upper) and 2 qi (lower)
@@ -1284,13 +1302,17 @@ DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, co
         }
         if (dir == 0) {
             green_planes(1);
+            SSTAMP(7);
             __syncthreads();
+            SSTAMP(8);
         } else if (chained && tid < MPS) {
             reinterpret_cast<unsigned*>(vmap)[tid] = carry_vote[tid];      // vote rows m = 0, 1 (pixel rows -3, -2): the previous pass's rows 29, 30
         }
     }
 #undef MWAT
+    SSTAMP(11);
     __syncthreads();
+    SSTAMP(12);
     if (tid == 0 && p.float_form_tiles != nullptr && s_flag[2] != 0) atomicAdd(p.float_form_tiles, 1u);
 
     // ---- P4: thread rows 0..14 select their own quad row, thread row 15 the row stashed by the previous pass (quad row Q0 - 1); then the stash takes row 15's candidates
@@ -1358,6 +1380,7 @@ DEVI void ahd_stream_pass(const int tbx_in, const int Q0, const bool chained, co
     }
     // the votes of pixel rows 29, 30 (rows m = 32, 33) for the next pass
     if (tid < MPS) carry_vote[tid] = reinterpret_cast<const unsigned*>(vmap)[(SMPR - 2) * (MPS / 2) + tid];
+    SSTAMP(13);
 }
 }  // namespace
 

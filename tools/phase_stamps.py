@@ -28,12 +28,15 @@ NAMES = ["P0 tile load + plane store", "barrier", "P1(H) green planes", "barrier
 
 def main() -> None:
     H, W = 4000, 6000
+    stream = "--stream" in sys.argv          # the streaming form of the select kernel (round 5): stamps accumulate per wave over its passes
     L = _lib.lib()
     if not hasattr(L, "pysp_debug_ahd_stamps"):
         raise SystemExit("this library has no stamps: build with -DAHD_STAMPS and point PYSP_HIP_LIB at it")
     L.pysp_debug_ahd_stamps.restype = ctypes.c_int
     L.pysp_debug_ahd_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     ctx = _lib.Context(0)
+    ctx.set_lab_layout("packed")
+    ctx.set_select_form("stream" if stream else "tile")
     wbobj = default_wb()
     wb, M = _lib.wb3(wbobj.get_reciprocal_multipliers()), _lib.mat9(final_matrix(wbobj.get_matrix()))
     frame = torch.from_numpy(rggb_frame(H, W, 1000)).cuda()
@@ -47,12 +50,21 @@ def main() -> None:
     nst = L.pysp_debug_ahd_stamps(None, 0, 1)           # clear
     step()
     ctx.sync()
-    n_waves = ((W // 2 + 13) // 14) * ((H // 2 + 13) // 14) * 4
+    n_waves = (1 << 17) if stream else ((W // 2 + 13) // 14) * ((H // 2 + 13) // 14) * 4
     buf = np.zeros(n_waves * nst, dtype=np.uint64)
     assert L.pysp_debug_ahd_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size, 0) == nst
-    st = buf.reshape(n_waves, nst)[:, :14].astype(np.int64)
-    ok = (st > 0).all(axis=1)
-    st = st[ok]
+    if stream:
+        # per wave: sums over its passes of (clock at boundary i - clock at the pass's first stamp), slot 15 = passes -> mean cycles per pass
+        raw = buf.reshape(n_waves, nst).astype(np.float64)
+        raw = raw[raw[:, 15] > 0]
+        passes = raw[:, 15]
+        st = (raw[:, :14] / passes[:, None])
+        print(f'"streaming form: waves {len(st)}, passes per wave mean {passes.mean():.2f} / min {passes.min():.0f} / max {passes.max():.0f}; figures are mean cycles PER PASS; the first interval includes the wait at the pass-top barrier",,,,')
+        ok = np.ones(len(st), bool)
+    else:
+        st = buf.reshape(n_waves, nst)[:, :14].astype(np.int64)
+        ok = (st > 0).all(axis=1)
+        st = st[ok]
     d = np.diff(st, axis=1)                                # 13 intervals
     life = st[:, 13] - st[:, 0]
     print("interval,mean_cycles,median_cycles,p90_cycles,share_of_wave_lifetime")
