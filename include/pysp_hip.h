@@ -196,6 +196,10 @@ int pysp_wb_scale_dev(pysp_ctx *ctx, const float *d_in, size_t npx, const float 
 /* ---- Fused recipe (README.md:55-63): demosaic -> to_lin_srgb (clip on) -> [x/(1+x), README.md:157]
  * -> lin_srgb_to_srgb, one frame, no intermediate leaves the GPU.  srgb: (H,W,3) float32. */
 int pysp_pipeline_srgb_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *srgb);
+/* The same host-buffer pipeline with any colour tail (0 RawDemosaicData.image, base_types/image_base.py:27; 1 to_lin_srgb, :62-64; 2 + lin_srgb_to_srgb,
+ * colorize/transform.py:89-99; 3 with README.md:157's x/(1+x) in between): what the drop-in classes' deferred mode (pysp_amd.set_lazy("deferred")) collapses
+ * demosaic() -> to_lin_srgb() [-> lin_srgb_to_srgb()] into -- one upload overlapped with the kernels and the download, in bands. */
+int pysp_pipeline_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *out);
 int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *d_srgb);
 
 /* General form: tail 0 = pysp_demosaic_dev, 1 = + to_lin_srgb (clip + CCM; BASELINE config 3 "debayer + WB + CCM"),

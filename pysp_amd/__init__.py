@@ -5,7 +5,7 @@ error behaviour); all pixel work happens in hand-written HIP kernels reached thr
 `pysp_amd/csrc/libpysp_hip.so` (include/pysp_hip.h).  There is no CPU fallback.
 """
 from .const import QualityDemosaic, PatternDemosaic  # noqa: F401
-from .device_array import DeviceArray, lazy_enabled, set_lazy  # noqa: F401
+from .device_array import DeferredImage, DeviceArray, deferred_enabled, lazy_enabled, set_lazy  # noqa: F401
 
-__all__ = ["QualityDemosaic", "PatternDemosaic", "DeviceArray", "set_lazy", "lazy_enabled"]
+__all__ = ["QualityDemosaic", "PatternDemosaic", "DeviceArray", "DeferredImage", "set_lazy", "lazy_enabled", "deferred_enabled"]
 __version__ = "0.1.0"

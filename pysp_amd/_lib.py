@@ -78,6 +78,7 @@ _SIGNATURES = {
     "pysp_wb_scale_f32": (_int, [_vp, _vp, _sz, _f32p, _int, _vp]),
     "pysp_pipeline_srgb_f32": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
     "pysp_pipeline_srgb_dev": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
+    "pysp_pipeline_f32": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
     "pysp_pipeline_dev": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
     "pysp_pipeline_batch_dev": (_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _int, _int, _int, _f32p, _f64p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p)]),
     "pysp_pipeline_u16_f32": (_int, [_vp, _vp, _int, _int, _f32p, _f32p, _f32p, _f64p, _int, _int, _int, _int, _vp]),

@@ -10,17 +10,30 @@ import ctypes
 import numpy as np
 
 from .. import _lib
-from ..device_array import DeviceArray, lazy_enabled
+from ..device_array import DeferredImage, DeviceArray, lazy_enabled
 from ..wb_cct.helpers_cam_mat import MatXyzToCamera
 from .rgb_space import ArbitraryRgbColorspace, LinRgbColorspace
 
 
+_FINAL_MATRIX_CACHE: dict = {}
+
+
 def final_matrix(cam_xyz_matrix: MatXyzToCamera, destination_colorspace: ArbitraryRgbColorspace = LinRgbColorspace.REC709) -> np.ndarray:
-    """inv(row-normalised(XYZ->cam @ RGB->XYZ adapted to the camera white)), float64 (transform.py:40-49)."""
+    """inv(row-normalised(XYZ->cam @ RGB->XYZ adapted to the camera white)), float64 (transform.py:40-49).  The same nine doubles for the same camera matrix,
+    white and colourspace: the last few results are kept (the recipe asks twice per frame -- AHD's homogeneity metric and to_lin_srgb -- and a 3x3 inverse plus
+    the Bradford chain cost more host time than enqueueing the frame's kernels); a fresh copy is returned, as the reference returns a fresh array."""
+    key = (np.asarray(cam_xyz_matrix.mat).tobytes(), np.asarray(cam_xyz_matrix.xyz).tobytes(), np.asarray(cam_xyz_matrix.mat).dtype.str, id(destination_colorspace))
+    hit = _FINAL_MATRIX_CACHE.get(key)
+    if hit is not None and hit[0] is destination_colorspace:
+        return hit[1].copy()
     to_xyz = destination_colorspace.mat_to_xyz(cam_xyz_matrix.xyz.tolist())
     m = np.matmul(cam_xyz_matrix.mat, to_xyz)
     m = m / m.sum(axis=1)[:, np.newaxis]        # neutral in -> neutral out
-    return np.linalg.inv(m)
+    out = np.linalg.inv(m)
+    if len(_FINAL_MATRIX_CACHE) >= 16:
+        _FINAL_MATRIX_CACHE.pop(next(iter(_FINAL_MATRIX_CACHE)))
+    _FINAL_MATRIX_CACHE[key] = (destination_colorspace, out.copy())
+    return out
 
 
 def _on_device(x) -> bool:
@@ -42,6 +55,9 @@ def clip_rgb(rgb: np.ndarray) -> np.ndarray:
 def cam_to_rgb_norm(rgb: np.ndarray, cam_xyz_matrix: MatXyzToCamera, destination_colorspace: ArbitraryRgbColorspace,
                     clip_highlights: bool = True) -> np.ndarray:
     M = final_matrix(cam_xyz_matrix, destination_colorspace)
+    if isinstance(rgb, DeferredImage) and rgb.pending and lazy_enabled() and clip_highlights and rgb.plan["tail"] == 0 and \
+            (rgb.plan["M"] is None or np.array_equal(rgb.plan["M"], M)):
+        return rgb.with_tail(1, M)                   # deferred mode: the pending demosaic grows a colour tail, still nothing runs
     if _on_device(rgb):                              # intermediate of the README recipe: stays in HBM (lazy DeviceArray)
         if rgb.ndim != 3 or rgb.shape[2] != 3:
             raise ValueError("expected an (H, W, 3) RGB image")
@@ -79,6 +95,8 @@ def _flat(fn_name: str, x: np.ndarray) -> np.ndarray:
 def lin_srgb_to_srgb(rgb: np.ndarray) -> np.ndarray:
     """Clip to [0,1] and apply the sRGB transfer curve (transform.py:89-99).  Always returns a real ndarray: given the lazy
     result of to_lin_srgb() it encodes on the GPU and downloads once (the end of the README recipe)."""
+    if isinstance(rgb, DeferredImage) and rgb.pending and lazy_enabled() and rgb.plan["tail"] == 1:
+        return rgb.with_tail(2, rgb.plan["M"]).numpy()      # deferred mode: the whole README recipe as ONE banded host call
     if _on_device(rgb):
         if rgb.ndim != 3 or rgb.shape[2] != 3:
             raise ValueError("expected an (H, W, 3) RGB image")

@@ -919,6 +919,11 @@ int pysp_pipeline_srgb_f32(pysp_ctx* ctx, const float* bayer, int H, int W, cons
     CTX_ENTER(ctx);
     return run_pipeline_host(ctx, bayer, H, W, wb, M, quality, hdr, stages, reinhard ? 3 : 2, srgb);
 }
+int pysp_pipeline_f32(pysp_ctx* ctx, const float* bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float* out) {
+    CTX_ENTER(ctx);
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline: tail must be 0..3");
+    return run_pipeline_host(ctx, bayer, H, W, wb, M, quality, hdr, stages, tail, out);
+}
 int pysp_pipeline_srgb_dev(pysp_ctx* ctx, const float* d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float* d_srgb) {
     CTX_ENTER(ctx);
     return run_pipeline_dev(ctx, d_bayer, H, W, wb, M, quality, hdr, stages, reinhard ? 3 : 2, d_srgb);

@@ -6,7 +6,7 @@ import numpy as np
 from .. import _lib
 from ..base_types.image_base import RawDemosaicData, RawRggbBayerData_BaseType
 from ..colorize.transform import final_matrix
-from ..device_array import DeviceArray, lazy_enabled
+from ..device_array import DeferredImage, DeviceArray, deferred_enabled, lazy_enabled
 from .ahd_homogeneity import build_map  # noqa: F401
 
 
@@ -21,7 +21,11 @@ def _run(image: RawRggbBayerData_BaseType, quality: int, stages: int = 0) -> Raw
     mat = image.cam_wb.get_matrix()
     # The matrix only matters for AHD's homogeneity metric (ahd.py:46-48).
     M = _lib.mat9(final_matrix(mat)) if quality == _lib.QUALITY_BEST else None
-    if lazy_enabled():
+    if deferred_enabled():
+        # opt-in (pysp_amd.set_lazy("deferred")): nothing runs yet -- the README recipe collapses into one banded host call when its result is read
+        Mf = final_matrix(mat) if quality == _lib.QUALITY_BEST else None
+        rgb = DeferredImage(_lib.default_context(), bayer, wb, Mf, quality, bool(image.get_hdr()), int(stages), 0)
+    elif lazy_enabled():
         # the result stays in HBM (DeviceArray) until somebody reads RawDemosaicData.image; to_lin_srgb() consumes it there
         ctx = _lib.default_context()
         src = DeviceArray.from_host(ctx, bayer)

@@ -27,15 +27,25 @@ import numpy as np
 from . import _lib
 
 _lazy = os.environ.get("PYSP_EAGER", "0") in ("", "0")
+_deferred = os.environ.get("PYSP_LAZY", "") == "deferred"
 
 
-def set_lazy(on: bool) -> None:
-    global _lazy
+def set_lazy(on) -> None:
+    """True (default): results stay in HBM until read.  False: every call returns plain ndarrays, like the reference.  "deferred": as True, and a demosaic of a
+    host mosaic is not even started until its result (or what to_lin_srgb() / lin_srgb_to_srgb() make of it) is needed -- the README recipe then runs as ONE
+    banded host call whose upload, kernels and download overlap (5.9 ms instead of 7.7 ms at 24 MP).  The price, and why it is opt-in: until then the result
+    REFERS to the caller's mosaic (`sensor_scaled`), so that array must not be modified in between (the reference computes eagerly and would not see the edit)."""
+    global _lazy, _deferred
+    _deferred = on == "deferred"
     _lazy = bool(on)
 
 
 def lazy_enabled() -> bool:
     return _lazy
+
+
+def deferred_enabled() -> bool:
+    return _lazy and _deferred
 
 
 class DeviceArray:
@@ -155,6 +165,86 @@ class DeviceArray:
         if name.startswith("_"):
             raise AttributeError(name)
         return getattr(self.numpy(), name)
+
+
+class DeferredImage(DeviceArray):
+    """The (H, W, 3) result of a demosaic of a HOST mosaic that has not run yet (pysp_amd.set_lazy("deferred")): it remembers the mosaic (by reference), the
+    white balance, matrix, quality, HDR flag, median stages and a colour tail (0 camera RGB, 1 to_lin_srgb, 2 + lin_srgb_to_srgb).  Needed on the host
+    (numpy(), np.asarray, .image, lin_srgb_to_srgb) it runs the whole chain as one banded host call (pysp_pipeline_f32: upload || kernels || download);
+    needed on the device (wb_undo(), a fusion, another colourspace) it uploads and runs the kernels there and from then on is an ordinary DeviceArray."""
+
+    def __init__(self, ctx, mosaic: np.ndarray, wb, M, quality: int, hdr: bool, stages: int, tail: int = 0):
+        H, W = mosaic.shape
+        self._ctx = ctx
+        self.shape = (int(H), int(W), 3)
+        self.dtype = np.dtype(np.float32)
+        self._host = None
+        self._keepalive = None
+        self._ptr = None
+        self._plan = {"mosaic": mosaic, "wb": np.asarray(wb, dtype=np.float32).copy(), "M": None if M is None else np.array(M, dtype=np.float64).reshape(3, 3),
+                      "quality": int(quality), "hdr": bool(hdr), "stages": int(stages), "tail": int(tail)}
+
+    @property
+    def pending(self) -> bool:
+        return self._plan is not None
+
+    @property
+    def plan(self):
+        return self._plan
+
+    def with_tail(self, tail: int, M) -> "DeferredImage":
+        """The same pending demosaic followed by colour tail `tail` with matrix M (a NEW array: this one keeps standing for what it stood for)."""
+        p = self._plan
+        return DeferredImage(self._ctx, p["mosaic"], p["wb"], M, p["quality"], p["hdr"], p["stages"], tail)
+
+    def _args(self):
+        p = self._plan
+        H, W = p["mosaic"].shape
+        return H, W, _lib.wb3(p["wb"]), _lib.mat9(p["M"]), p["quality"], int(p["hdr"]), p["stages"], p["tail"]
+
+    @property
+    def on_device(self) -> bool:
+        return self._plan is not None or bool(self._ptr)
+
+    @property
+    def ptr(self) -> ctypes.c_void_p:
+        if self._plan is not None:                      # somebody needs it in HBM: upload, run, become an ordinary device array
+            with self._ctx.lock:
+                if self._plan is not None:
+                    H, W, wb, M, q, hdr, st, tail = self._args()
+                    src = DeviceArray.from_host(self._ctx, self._plan["mosaic"])
+                    dptr = _lib.lib().pysp_dev_alloc(self._ctx.handle, ctypes.c_size_t(self.nbytes))
+                    if not dptr:
+                        raise MemoryError(_lib.last_error())
+                    self._ptr = int(dptr)
+                    call = _lib.lib().pysp_demosaic_dev if tail == 0 else None
+                    if call is not None:
+                        _lib.check(call(self._ctx.handle, src.ptr, H, W, wb, M, q, hdr, st, ctypes.c_void_p(self._ptr)))
+                    else:
+                        _lib.check(_lib.lib().pysp_pipeline_dev(self._ctx.handle, src.ptr, H, W, wb, M, q, hdr, st, tail, ctypes.c_void_p(self._ptr)))
+                    self._keepalive = self._plan["mosaic"]
+                    src.release()
+                    self._plan = None
+        return super().ptr
+
+    def numpy(self) -> np.ndarray:
+        if self._host is None and self._plan is not None:
+            out = _lib.empty_f32(self.shape)
+            with self._ctx.lock:
+                if self._host is None and self._plan is not None:
+                    H, W, wb, M, q, hdr, st, tail = self._args()
+                    _lib.check(_lib.lib().pysp_pipeline_f32(self._ctx.handle, _lib.ptr(self._plan["mosaic"]), H, W, wb, M, q, hdr, st, tail, _lib.ptr(out)))
+                    self._host = out
+                    self._plan = None
+            return self._host
+        return super().numpy()
+
+    def release(self) -> None:
+        self._plan = None
+        super().release()
+
+    def __repr__(self):
+        return f"DeferredImage(shape={self.shape}, float32, {'pending: ' + str({k: v for k, v in self._plan.items() if k not in ('mosaic', 'M', 'wb')}) if self._plan else 'realised'})"
 
 
 def _delegate(name):

@@ -39,9 +39,12 @@ def unpack_params(block: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return block[:3].astype(np.float32), block[3:].reshape(3, 3).copy()
 
 
-def broadcast_params(wb, M, src: int = 0, device=None):
+def broadcast_params(wb, M, src: int = 0, device=None, group=None):
     """Broadcast (wb, M) from `src` to every rank of the default process group; returns them on all ranks.
-    Ranks other than `src` may pass None for both.  Without an initialised group it is the identity."""
+    Ranks other than `src` may pass None for both.  Without an initialised group it is the identity.
+    `group`: a pysp_amd._rccl.RcclGroup runs the broadcast over RCCL without torch (a NumPy / C caller's path)."""
+    if group is not None and hasattr(group, "broadcast_params"):
+        return group.broadcast_params(wb, M, src)
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -226,4 +229,45 @@ def demosaic_warp_banded(pipe, bayer_host: np.ndarray, wb, M, coeffs, centre, st
     sub = torch.from_numpy(np.ascontiguousarray(bayer_host[plan.r0:plan.r1])).to(pipe.device)
     band = demosaic_warp_banded_dev(pipe, sub, plan, wb, M, coeffs, centre, scale, group, exchange, via_host)
     pipe.sync()
+    return plan.y0, plan.y1, band
+
+
+def demosaic_warp_banded_np(ctx, bayer_host: np.ndarray, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0, group=None, exchange: str = "needed"):
+    """`demosaic_warp_banded` for a caller WITHOUT torch (pySP itself has no torch dependency): `ctx` is this rank's pysp_amd._lib.Context, `group` a
+    pysp_amd._rccl.RcclGroup (None: one rank), device memory comes from the context (pysp_dev_alloc).  Same three steps -- AHD(stages) of the band from host
+    rows with halo, exchange of the rows the warp needs (RCCL send/recv on raw device pointers), WarpRectilinear of the band -- and the same bits.
+    Returns (y0, y1, band) with band = rows [y0, y1) of the warped frame as a float32 ndarray."""
+    import ctypes
+    from . import _lib
+    from .device_array import DeviceArray
+    rank, world = (group.rank, group.world) if group is not None else (0, 1)
+    bay = _lib.f32c(bayer_host)
+    H, W = bay.shape
+    plan = BandPlan(H, W, world, rank, stages)
+    L = _lib.lib()
+    sub_h = np.ascontiguousarray(bay[plan.r0:plan.r1])
+    sub = DeviceArray.from_host(ctx, sub_h)
+    full, out = DeviceArray(ctx, (H, W, 3)), DeviceArray(ctx, (H, W, 3))
+    row_bytes = W * 12
+    # the band's demosaic lands where its rows live in the whole-frame buffer (its halo rows too: rows other ranks own, overwritten by the exchange if the warp needs them)
+    _lib.check(L.pysp_demosaic_dev(ctx.handle, sub.ptr, plan.r1 - plan.r0, W, _lib.wb3(wb), _lib.mat9(M), _lib.QUALITY_BEST, 0, int(stages),
+                                   ctypes.c_void_p(full.ptr.value + plan.r0 * row_bytes)))
+    cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+    cptr = cf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    if world > 1:
+        if exchange == "needed":
+            s0, s1 = ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(L.pysp_warp_source_rows(ctx.handle, H, W, cptr, cf.shape[0], float(centre[0]), float(centre[1]), float(scale), plan.y0, plan.y1, ctypes.byref(s0), ctypes.byref(s1)))
+            needs = group.all_gather_pairs(s0.value, s1.value)
+            group.exchange_rows(full.ptr.value, row_bytes, plan_row_exchange(plan.bands, needs))
+        elif exchange == "allgather":
+            group.allgather_bands(full.ptr.value, row_bytes, plan.bands)
+        else:
+            raise ValueError("exchange must be 'needed' or 'allgather'")
+    _lib.check(L.pysp_warp_rectilinear_rows_dev(ctx.handle, full.ptr, out.ptr, H, W, cptr, cf.shape[0], float(centre[0]), float(centre[1]), float(scale), plan.y0, plan.y1))
+    band = np.empty((plan.y1 - plan.y0, W, 3), np.float32)
+    with ctx.lock:
+        _lib.check(L.pysp_dev_download(ctx.handle, _lib.ptr(band), ctypes.c_void_p(out.ptr.value + plan.y0 * row_bytes), ctypes.c_size_t(band.nbytes)))
+    for d in (sub, full, out):
+        d.release()
     return plan.y0, plan.y1, band

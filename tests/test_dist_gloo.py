@@ -285,3 +285,27 @@ def test_config5_band_and_exchange_plan_world8_real_geometry():
         assert biggest <= 60 and reach <= 1                                             # neighbours only, <= 60 rows per transfer
         assert recv <= 120 and recv < (H - (y1 - y0)) // 50                             # all-gather: H - band rows received per rank
     assert sum(r[6] for r in res) == sum(r[7] for r in res) > 0
+
+
+def test_rccl_rendezvous_without_torch_or_gpu():
+    """pysp_amd._rccl.exchange_unique_id: rank 0 serves the 128-byte ncclUniqueId over TCP (MASTER_ADDR / a port derived from MASTER_PORT), every rank
+    returns the same bytes -- late joiners retry until the server is up.  Plain sockets: this part of the torch-free RCCL path runs anywhere."""
+    import socket
+    import threading
+    import time
+    from pysp_amd._rccl import NCCL_UNIQUE_ID_BYTES, exchange_unique_id
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    payload = bytes(range(128))
+    assert len(payload) == NCCL_UNIQUE_ID_BYTES
+    got = {}
+
+    def run(rank, delay):
+        time.sleep(delay)
+        got[rank] = exchange_unique_id(rank, 4, payload if rank == 0 else None, "127.0.0.1", port, timeout=30.0)
+    ts = [threading.Thread(target=run, args=(r, d)) for r, d in ((1, 0.0), (2, 0.0), (0, 0.3), (3, 0.5))]      # two ranks knock before rank 0 listens
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert got == {r: payload for r in range(4)}
+    assert exchange_unique_id(0, 1, payload) == payload

@@ -11,6 +11,12 @@ def _wbM(orc):
     return (1.0 / MULT).astype(np.float32), orc.final_matrix(XYZ2CAM, orc.xy_to_XYZ(D65_XY))
 
 
+@pytest.fixture()
+def wbobj():
+    from pysp_amd.synth import default_wb
+    return default_wb()
+
+
 # frame sizes around every boundary of the streaming select kernel: one head pass (<= 14 quad rows), head + chained passes (14 + 16 m rows and one more / fewer),
 # the flush pass (a column whose last row is the stashed one: 14 + 16 m + 16 rows), several column tiles, partial tiles right and below, many chunks per column
 STREAM_SIZES = [(8, 8), (10, 30), (28, 28), (30, 30), (32, 60), (58, 34), (60, 28), (62, 90), (64, 56), (92, 40), (94, 118), (120, 176), (124, 30),
@@ -130,3 +136,141 @@ def test_automatic_lab_layout_on_alternating_content(orc):
     rows = measure((4000, 6000), 900)
     for r in rows:
         assert r["auto_over_best_fixed"] <= 1.05, rows
+
+
+def test_deferred_recipe_equals_eager_recipe(orc, wbobj):
+    """pysp_amd.set_lazy("deferred") (opt-in): demosaic() of a host mosaic starts nothing, to_lin_srgb() / lin_srgb_to_srgb() extend the pending chain, and the
+    README recipe (README.md:55-63 of the reference) runs as ONE banded host call -- same bits as the default (eager upload, lazy download) mode and as the
+    oracle, for every quality; reading .image, wb_undo(), another colourspace and a non-RGGB pattern take the pending result wherever they need it."""
+    import pysp_amd
+    from pysp_amd.base_types.image_base import BayerPattern
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.colorize.rgb_space import LinRgbColorspace
+    from pysp_amd.colorize.transform import cam_to_rgb_norm
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.device_array import DeferredImage
+    from pysp_amd.image import RawBayerData, RawRggbBayerData
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    bay = rggb_frame(2100, 2600, 1000)                  # > 4 MP: the host pipeline runs in bands
+    small = rggb_frame(120, 176, 3)
+
+    def recipe(frame, q, steps=1):
+        raw = RawRggbBayerData(frame, wbobj, 10.0, 1.0)
+        d = raw.demosaic(q, steps)
+        lin = d.to_lin_srgb()
+        return d, lin, lin_srgb_to_srgb(lin)
+    try:
+        for frame in (small, bay):
+            for q in (QualityDemosaic.Draft, QualityDemosaic.Fast, QualityDemosaic.Best):
+                pysp_amd.set_lazy(True)
+                d0, lin0, s0 = recipe(frame, q)
+                img0, lin0 = np.array(d0.image), np.asarray(lin0)
+                pysp_amd.set_lazy("deferred")
+                d1, lin1, s1 = recipe(frame, q)
+                assert isinstance(lin1, DeferredImage) and lin1.pending and isinstance(d1._dev, DeferredImage) and d1._dev.pending     # nothing has run but the fused call
+                assert isinstance(s1, np.ndarray) and np.array_equal(s1, s0, equal_nan=True), q
+                assert np.array_equal(np.asarray(lin1), lin0) and not lin1.pending                 # the linear image on its own: a second fused call, tail 1
+                assert np.array_equal(d1.image, img0)                                               # and the camera RGB: tail 0
+        ref = orc.pipeline_srgb(small, wb, M, 2, False, 1, False)
+        pysp_amd.set_lazy("deferred")
+        assert np.array_equal(recipe(small, QualityDemosaic.Best)[2], ref)
+        # device-side consumers realise the pending demosaic in HBM: wb_undo, another colourspace
+        d = RawRggbBayerData(small, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Best)
+        d.wb_undo()
+        pysp_amd.set_lazy(True)
+        e = RawRggbBayerData(small, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Best)
+        e.wb_undo()
+        assert np.array_equal(d.image, e.image)
+        pysp_amd.set_lazy("deferred")
+        d = RawRggbBayerData(small, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Fast)
+        a = np.asarray(cam_to_rgb_norm(d._device_image(), d.mat_xyz, LinRgbColorspace.REC2020))
+        pysp_amd.set_lazy(True)
+        e = RawRggbBayerData(small, wbobj, 10.0, 1.0).demosaic(QualityDemosaic.Fast)
+        assert np.array_equal(a, np.asarray(cam_to_rgb_norm(e._device_image(), e.mat_xyz, LinRgbColorspace.REC2020)))
+        # a non-RGGB sensor: the flip back reads .image (image.py:181)
+        for mode in ("deferred", True):
+            pysp_amd.set_lazy(mode)
+            rb = RawBayerData()
+            rb.sensor_scaled, rb.cam_wb, rb.current_ev, rb.lim_sat, rb.sensor_pattern = small, wbobj, 10.0, 1.0, BayerPattern.Bggr
+            out = np.array(rb.demosaic(QualityDemosaic.Best).image)
+            if mode == "deferred":
+                first = out
+        assert np.array_equal(first, out)
+    finally:
+        pysp_amd.set_lazy(True)
+
+
+def test_fusion_keeps_an_exposure_whose_lazy_image_was_read_elsewhere(orc, wbobj):
+    """an exposure may hold a DeviceArray whose device copy another holder has released (np.asarray on the shared lazy result moves it to the
+    host).  is_valid() counted such an exposure as empty and fuse_exposures_from_debayer dropped it silently; it still resolves through .image and is fused."""
+    from pysp_amd.base_types.image_base import RawDemosaicData
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.raw_hdr import fuse_exposures_from_debayer
+    from pysp_amd.synth import rggb_frame
+    frames = [np.clip(rggb_frame(64, 96, 5, scale=4.0, clip_hi=False) * np.float32(2.0 ** -k), 0, 1).astype(np.float32) for k in range(3)]
+
+    def exposures():
+        out = []
+        for k, f in enumerate(frames):
+            d = RawRggbBayerData(f, wbobj, 10.0 + k, 1.0).demosaic(QualityDemosaic.Fast)
+            out.append(d)
+        return out
+    ref_exp = exposures()
+    want, want_cnt = fuse_exposures_from_debayer(ref_exp)
+    exp = exposures()
+    shared = exp[1]._dev                                  # a second holder of exposure 1's lazy result ...
+    host = np.asarray(shared)                             # ... reads it: the device copy is released, the array lives on the host now
+    assert not shared.on_device and exp[1]._img is None and exp[1].is_valid()
+    got, cnt = fuse_exposures_from_debayer(exp)
+    assert np.array_equal(np.asarray(got), np.asarray(want)) and np.array_equal(np.asarray(cnt), np.asarray(want_cnt))
+    assert host.shape == (64, 96, 3)
+
+
+def test_rccl_group_without_torch_at_world_one(orc):
+    """the collectives of SURVEY.md 8e for a caller WITHOUT torch -- a ctypes binding of librccl.so (pysp_amd/_rccl.py: ncclCommInitRank,
+    ncclBroadcast, ncclAllGather, grouped ncclSend / ncclRecv on raw device pointers) behind multi_gpu.broadcast_params and multi_gpu.demosaic_warp_banded_np.
+    A child process that never imports torch runs them at world size 1 on the GPU (the gloo tests of tests/test_dist_gloo.py are the semantic twin for
+    N > 1) and writes its band; here the band is compared with the torch path's whole-frame result, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import torch
+    from pysp_amd.pipeline import DevicePipeline
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    H, W = 200, 300
+    coeffs = np.array([[1.0, 0.05, 0.01, 0.0, 0.001, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0, 0.0], [0.98, -0.04, 0.01, 0.0, 0.0, 0.002]])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), wb=wb, M=M, coeffs=coeffs)
+        code = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from pysp_amd import _lib, _rccl
+from pysp_amd.multi_gpu import broadcast_params, demosaic_warp_banded_np
+from pysp_amd.synth import rggb_frame
+d = np.load({os.path.join(tmp, 'in.npz')!r})
+ctx = _lib.Context(0)
+g = _rccl.RcclGroup(0, 1, ctx)
+wb, M = broadcast_params(d['wb'], d['M'], 0, group=g)
+assert np.array_equal(wb, d['wb']) and np.array_equal(M, d['M'])
+assert g.all_gather_pairs(7, 11) == [(7, 11)]
+y0, y1, band = demosaic_warp_banded_np(ctx, rggb_frame({H}, {W}, 1000), wb, M, d['coeffs'], (0.5, 0.48), stages=3, group=g)
+for ex in ('needed', 'allgather'):
+    assert np.array_equal(demosaic_warp_banded_np(ctx, rggb_frame({H}, {W}, 1000), wb, M, d['coeffs'], (0.5, 0.48), stages=3, group=g, exchange=ex)[2], band)
+g.destroy()
+assert 'torch' not in sys.modules, 'the torch-free path imported torch'
+np.save({os.path.join(tmp, 'band.npy')!r}, band)
+print(y0, y1)
+"""
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[-2:] == ["0", str(H)]
+        band = np.load(os.path.join(tmp, "band.npy"))
+    pipe = DevicePipeline(0)
+    ref = pipe.demosaic_warp(torch.from_numpy(rggb_frame(H, W, 1000)).cuda(), wb, M, coeffs, (0.5, 0.48), stages=3)
+    pipe.sync()
+    assert np.array_equal(band, ref.cpu().numpy())
