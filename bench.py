@@ -455,6 +455,8 @@ def main() -> None:
     roofline = None
     if dom:
         px_per_launch = H * W
+        if batched and quality in (0, 1) and os.environ.get("PYSP_BATCH_GRID", "1") != "0":
+            px_per_launch = H * W * min(frames_per_step, 16)      # Draft / EAG batches run as ONE grid per 16 frames (round 5); AHD batches frame by frame
         if args.workload == "cfg5" and dom != "k_warp_remap":
             px_per_launch = (plan.r1 - plan.r0) * W               # a band kernel processes the band plus its halo rows
         elif args.workload == "cfg5":
@@ -572,6 +574,7 @@ def main() -> None:
     if not args.no_cpu_baseline and quality >= 0 and args.workload != "cfg5":
         try:
             from oracle import oracle
+            oracle.set_lab_mode(0 if args.lab_mode == "closed_form" else 1)      # the checker votes on the same restatement of cv2.cvtColor as the context (--lab-mode)
             Mo = p[3:].reshape(3, 3)
             wbo = p[:3].astype(np.float32)
             u16 = args.workload.endswith("u16")
@@ -635,6 +638,7 @@ def main() -> None:
     if not args.no_cpu_baseline and verify is None and (quality < 0 or args.workload == "cfg5"):
         try:
             from oracle import oracle
+            oracle.set_lab_mode(0 if args.lab_mode == "closed_form" else 1)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
 
             def baseline(mp, dt, what):

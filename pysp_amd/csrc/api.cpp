@@ -787,8 +787,16 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     static const bool d2h_sync = [] { const char* e = getenv("PYSP_D2H_SYNC"); return e && e[0] == '1'; }();             // experiment: helper thread downloads with the blocking hipMemcpy
     struct Registered {
         void* p = nullptr;
-        ~Registered() { if (p) { hipError_t e = hipHostUnregister(p); (void)e; } }
+        pysp_ctx* c = nullptr;
+        ~Registered() {
+            if (!p) return;
+            // every return path: no DMA may still read the pages when they are unlocked (the regular path has drained the streams already: these waits cost nothing there)
+            hipError_t e = hipStreamSynchronize(c->up_stream); (void)e;
+            e = hipStreamSynchronize(c->stream); (void)e;
+            e = hipHostUnregister(p); (void)e;
+        }
     } reg;
+    reg.c = ctx;
     // A page-locked result takes asynchronous downloads; next to those the runtime's blocking upload from PAGEABLE memory either waits for them (event-chained
     // form: 0.53 ms per band instead of 0.12, 8.7 ms per 24 MP frame) or, issued from a second thread, lands on the downloads' DMA engine every other call
     // (helper-thread form: 5.8 / 7.0 ms, bimodal -- rounds 2-4's unexplained "pinned result is slower").  So the caller's mosaic is page-locked for the duration

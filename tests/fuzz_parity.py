@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity run (bit-exact): python tests/fuzz_parity.py [seconds] [seed]
 Test infrastructure (it calls the CPU oracle); a 10-second slice of it runs inside the GPU suite (test_gpu_parity.py::test_fuzz_slice).
 Random even frame sizes, value distributions (uniform, heavy-tailed, saturated, zeros, negatives, tiny), qualities, HDR flag,
-post-process stage counts, colour tails, Lab layout / Lab mode of the context, uint16 input, CA removal, raw fusion, WarpRectilinear (fused kernel vs its own tables through the oracle remap).  Stops at the first mismatch with a reproducer line."""
+post-process stage counts, colour tails, Lab layout / Lab mode / select-kernel form of the context, Draft / EAG batches in one grid, uint16 input, CA removal, raw fusion, WarpRectilinear (fused kernel vs its own tables through the oracle remap).  Stops at the first mismatch with a reproducer line."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,30 +66,38 @@ while time.time() < t_end:
         pipe.ctx.set_lab_layout(layout); cur_layout = layout
     lab_mode = 0 if np.random.default_rng(seed ^ 0x5EED).random() < 0.1 else 1
     pipe.ctx.set_lab_mode(lab_mode); orc.set_lab_mode(lab_mode)
+    # round 5: the form of the select kernel (tiles / streaming down the columns: same bits), from its own generator as well
+    form = ("tile", "stream")[int(np.random.default_rng(seed ^ 0xF0F0).integers(0, 2))]
+    pipe.ctx.set_select_form(form)
     if case == 0:      # AHD with stages / hdr
         stages, hdr = int(rng.integers(0, 4)), bool(rng.integers(0, 2))
         if nonfinite: stages = 0
         got = pipe.demosaic(d, wb, M, _lib.QUALITY_BEST, hdr, stages); pipe.sync()
         ref = orc.demosaic_ahd(bay, wb, M, hdr, stages)
-        tag = f"ahd stages={stages} hdr={hdr} layout={layout} lab_mode={lab_mode}"
+        tag = f"ahd stages={stages} hdr={hdr} layout={layout} lab_mode={lab_mode} form={form}"
     elif case == 1:    # fused pipeline to sRGB, any quality
         q, stages, hdr, rh = int(rng.integers(0, 3)), int(rng.integers(0, 3)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         if nonfinite: stages = 0
         got = pipe.demosaic_to_srgb(d, wb, M, q, hdr, stages, rh); pipe.sync()
         ref = orc.pipeline_srgb(bay, wb, M, q, hdr, stages, rh)
-        tag = f"srgb q={q} stages={stages} hdr={hdr} reinhard={rh} layout={layout} lab_mode={lab_mode}"
-    elif case == 2:    # EAG / Draft raw
+        tag = f"srgb q={q} stages={stages} hdr={hdr} reinhard={rh} layout={layout} lab_mode={lab_mode} form={form}"
+    elif case == 2:    # EAG / Draft raw; a third of the time as a batch of 2-5 frames in one grid (round 5), the LAST frame of the batch is the one compared
         q = int(rng.integers(0, 2))
-        got = pipe.demosaic(d, wb, M, q, False, 0); pipe.sync()
+        nb = int(rng.integers(2, 6)) if rng.random() < 0.33 else 1
+        if nb == 1:
+            got = pipe.demosaic(d, wb, M, q, False, 0); pipe.sync()
+        else:
+            others = [torch.from_numpy(frame(rng, H, W)).cuda() for _ in range(nb - 1)]
+            got = pipe.batch(others + [d], wb, M, q, False, 0, 0)[-1]; pipe.sync()
         ref = orc.demosaic_eag(bay, wb) if q == 1 else orc.demosaic_draft(bay, wb)
-        tag = f"raw q={q}"
+        tag = f"raw q={q} batch={nb}"
     elif case == 3:    # uint16 loader
         raw = (rng.random((H, W)) * 16383).astype(np.uint16)
         black, sat = rng.uniform(0, 600, 4).astype(np.float32), rng.uniform(8000, 16383, 4).astype(np.float32)
         q = int(rng.integers(0, 3))
         got = pipe.raw_u16_to_rgb(torch.from_numpy(raw.view(np.int16)).cuda(), black, sat, wb, M, q, 1, 2); pipe.sync()
         ref = orc.pipeline_srgb(orc.bayer_normalize(raw, black, sat), wb, M, q, False, 1, False)
-        tag = f"u16 q={q} layout={layout} lab_mode={lab_mode}"
+        tag = f"u16 q={q} layout={layout} lab_mode={lab_mode} form={form}"
     elif case == 4:    # CA removal with random smooth quadrant fields
         if H < 4 or W < 4 or nonfinite:
             n += 1; continue
@@ -143,6 +151,7 @@ while time.time() < t_end:
         sys.exit(1)
     counts[tag.split()[0]] = counts.get(tag.split()[0], 0) + 1
     if tag.split()[0] in ("ahd", "srgb", "u16") and lab_mode == 1:
+        counts["form_" + form] = counts.get("form_" + form, 0) + 1
         k = "planes_kernel_next" if pipe.ctx.lab_layout_in_use() == 1 else "packed_kernel_next"      # what the policy / the switch selects after this case
         counts[k] = counts.get(k, 0) + 1
     n += 1

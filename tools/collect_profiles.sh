@@ -9,6 +9,8 @@ out=$root/gpurun_out/${tag}_final
 mkdir -p "$out"
 export TMPDIR=/tmp
 one() { python3 "$root/bench.py" "$@" 2>>"$out/bench.err" | grep '^{' ; }
+part=${2:-all}           # a: bench lines + kernel stats + workloads; b: hardware counters + host-path timings + microbenchmarks (two gpurun calls of <= 20 min each)
+if [ "$part" != b ]; then
 # 1. the driver's own command shape, then the default run
 one --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_20_5.json"
 one > "$out/bench.json"
@@ -32,6 +34,8 @@ for l in auto packed planes; do one --scene noise --lab-layout $l >> "$out/workl
 one --gpus 2 --backend gloo --workload cfg5 --steps 5 --warmup 2 >> "$out/workloads.jsonl"
 one --gpus 2 --backend gloo --workload cfg3 --steps 20 --warmup 3 >> "$out/workloads.jsonl"
 echo "workloads done"
+fi
+if [ "$part" = a ]; then echo "part a done"; exit 0; fi
 # 4. hardware counters of the default workload and of the EAG / Draft / warp kernels
 # (the Lab layout is pinned: under the automatic policy which select instance runs depends on the call history, and the summaries would mix two kernels -- ADVICE r4)
 bash "$root/tools/pmc_collect.sh" ${tag}_ahd24 --lab-layout packed > "$out/pmc_ahd24.log" 2>&1
