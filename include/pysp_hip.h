@@ -100,6 +100,11 @@ int pysp_ctx_lab_layout_in_use(pysp_ctx *ctx);
  * The default can be preset with the environment variable PYSP_SELECT_FORM (tile / stream). */
 int pysp_ctx_set_select_form(pysp_ctx *ctx, int form);
 int pysp_ctx_get_select_form(pysp_ctx *ctx);
+/* The work partition of form 1 for an H x W frame (host arithmetic, needs no GPU: the CPU tests check that the chunks tile every column exactly once):
+ * returns the number of chunks (or a negative error code) and, when out4 != NULL, writes { column tile, S, E, passes } per chunk -- output quad rows S + 1 .. E of
+ * that 14-quad-wide column, a head pass and passes - 1 chained ones -- in queue order; first[x] / count[x] = the range of XCD x's queue.
+ * slots_per_xcd: resident workgroups per queue the guided schedule assumes (the library itself uses CUs x occupancy / 8). */
+int pysp_ahd_stream_chunks(int H, int W, int slots_per_xcd, int *out4, int max_chunks, unsigned first[8], unsigned count[8]);
 int pysp_ctx_get_lab_lut(pysp_ctx *ctx, int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "pysp_ctx_lab_layout_in_use": (_int, [_vp]),
     "pysp_ctx_set_select_form": (_int, [_vp, _int]),
     "pysp_ctx_get_select_form": (_int, [_vp]),
+    "pysp_ahd_stream_chunks": (_int, [_int, _int, _int, _vp, _int, _vp, _vp]),
     "pysp_ctx_get_lab_lut": (_int, [_vp, _vp]),
     "pysp_ctx_set_stream": (_int, [_vp, _vp]),
     "pysp_ctx_get_stream": (_vp, [_vp]),

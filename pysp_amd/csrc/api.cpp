@@ -342,6 +342,18 @@ int pysp_ctx_set_select_form(pysp_ctx* ctx, int form) {
     return PYSP_OK;
 }
 int pysp_ctx_get_select_form(pysp_ctx* ctx) { return ctx ? ctx->select_form : -1; }
+int pysp_ahd_stream_chunks(int H, int W, int slots_per_xcd, int* out4, int max_chunks, unsigned first[8], unsigned count[8]) {
+    if (!even_dims(H, W) || H / 2 < 4 || W / 2 < 4 || !first || !count) return fail(PYSP_EBADARG, "stream_chunks: bad frame size %dx%d or null pointer", H, W);
+    std::vector<int4> chunks;
+    const unsigned passes = ahd_stream_chunks(H, W, slots_per_xcd, chunks, first, count);
+    const int n = (int)chunks.size() - 4;
+    if (out4) {
+        if (n > max_chunks) return fail(PYSP_EBADARG, "stream_chunks: %d chunks, room for %d", n, max_chunks);
+        for (int i = 0; i < n; i++) { out4[4 * i] = chunks[(size_t)i + 4].x; out4[4 * i + 1] = chunks[(size_t)i + 4].y; out4[4 * i + 2] = chunks[(size_t)i + 4].z; out4[4 * i + 3] = chunks[(size_t)i + 4].w; }
+    }
+    (void)passes;
+    return n;
+}
 int pysp_ctx_lab_layout_in_use(pysp_ctx* ctx) { return ctx ? (ctx->lab_layout == -1 ? ctx->layout_now : ctx->lab_layout) : -2; }
 
 int pysp_ctx_set_lab_lut(pysp_ctx* ctx, const int16_t* grid) {

@@ -1785,29 +1785,19 @@ __global__ void __launch_bounds__(NT_A, 1) k_ahd_fused(AhdParams a, MedParams m,
 // Chunk queues of the streaming select kernel for one frame size.  XCD x owns a contiguous range of column tiles; its columns are cut, top to bottom, into
 // chunks of 14 + 16 m quad rows (a head pass and m chained passes, m <= 7); m follows the work that is left in the queue (guided self-scheduling: the rows left
 // divided by twice the queue's workgroups), so the first chunks are long (15.7 output rows per pass) and the last ones single passes that fill the grid's drain.
-int ahd_stream_plan_build(AhdStreamPlan& plan, int H, int W, hipStream_t st) {
-    if (plan.H == H && plan.W == W && plan.d_chunks) return 0;
-    static int cus = 0, occ = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ahd_select_stream<false, false>, NT_A, 0) != hipSuccess || occ <= 0) occ = 6;
-        (void)hipGetLastError();
-    }
+// The schedule itself: pure host arithmetic (no GPU), exported for the CPU tests as pysp_ahd_stream_chunks.  chunks[0..3] = header (first[8], count[8]), then
+// { column tile, S, E, passes } per chunk; returns the number of passes of the launch.
+unsigned ahd_stream_chunks(int H, int W, int slots_per_xcd, std::vector<int4>& chunks, unsigned first[8], unsigned count[8]) {
     const int h = H / 2, w = W / 2, ncols = (w + TQX - 1) / TQX;
-    std::vector<int4> chunks(4);                                    // header: first[8], count[8]
+    chunks.assign(4, make_int4(0, 0, 0, 0));                        // header: first[8], count[8]
     unsigned passes = 0;
-    unsigned grid = (unsigned)(cus * occ) & ~7u;
-    // experiment switches (tools/ab_stream.sh): longest chunk 14 + 16 m rows, grid size, divisor of the guided schedule
+    // experiment switches (tools/ab_stream.sh): longest chunk 14 + 16 m rows, divisor of the guided schedule
     static const int env_maxm = [] { const char* e = getenv("PYSP_STREAM_MAXM"); return e ? atoi(e) : 7; }();
-    static const int env_grid = [] { const char* e = getenv("PYSP_STREAM_GRID"); return e ? atoi(e) : 0; }();
     static const int env_div = [] { const char* e = getenv("PYSP_STREAM_DIV"); return e && atoi(e) > 0 ? atoi(e) : 2; }();
-    if (env_grid > 0) grid = (unsigned)env_grid & ~7u;
-    if (grid < 8) grid = 8;
-    const long long slots = grid / 8;
+    const long long slots = slots_per_xcd > 0 ? slots_per_xcd : 1;
     for (int x = 0; x < 8; x++) {
         const int c0 = (int)((long long)ncols * x / 8), c1 = (int)((long long)ncols * (x + 1) / 8);
-        plan.first[x] = (unsigned)chunks.size() - 4u;
+        first[x] = (unsigned)chunks.size() - 4u;
         long long left = (long long)(c1 - c0) * h;
         for (int c = c0; c < c1; c++) {
             int r = 0;
@@ -1824,9 +1814,24 @@ int ahd_stream_plan_build(AhdStreamPlan& plan, int H, int W, hipStream_t st) {
                 r += len; left -= len;
             }
         }
-        plan.count[x] = (unsigned)chunks.size() - 4u - plan.first[x];
+        count[x] = (unsigned)chunks.size() - 4u - first[x];
     }
-    for (int x = 0; x < 8; x++) { reinterpret_cast<unsigned*>(chunks.data())[x] = plan.first[x]; reinterpret_cast<unsigned*>(chunks.data())[8 + x] = plan.count[x]; }
+    for (int x = 0; x < 8; x++) { reinterpret_cast<unsigned*>(chunks.data())[x] = first[x]; reinterpret_cast<unsigned*>(chunks.data())[8 + x] = count[x]; }
+    return passes;
+}
+int ahd_stream_plan_build(AhdStreamPlan& plan, int H, int W, hipStream_t st) {
+    if (plan.H == H && plan.W == W && plan.d_chunks) return 0;
+    static int cus = 0, occ = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ahd_select_stream<false, false>, NT_A, 0) != hipSuccess || occ <= 0) occ = 6;
+        (void)hipGetLastError();
+    }
+    unsigned slots = ((unsigned)(cus * occ) & ~7u) / 8;             // resident workgroups per XCD queue: what the guided schedule divides by
+    if (slots < 1) slots = 1;
+    std::vector<int4> chunks;
+    const unsigned passes = ahd_stream_chunks(H, W, (int)slots, chunks, plan.first, plan.count);
     // (an earlier launch may still read the old table)
     if (hipStreamSynchronize(st) != hipSuccess) return -3;
     if (plan.d_chunks) { (void)hipFree(plan.d_chunks); plan.d_chunks = nullptr; }

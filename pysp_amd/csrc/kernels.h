@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 struct MosaicSrc;   // demosaic_common.h: float32 mosaic, or raw uint16 + black/saturation levels
 MosaicSrc mosaic_f32(const float* d_bayer);
 MosaicSrc mosaic_u16(const uint16_t* d_bayer, const float black[4], const float sat[4]);
@@ -41,6 +43,8 @@ struct AhdStreamPlan {
     unsigned first[8] = {}, count[8] = {}, passes_total = 0, n_chunks = 0, grid = 0;
 };
 int ahd_stream_plan_build(AhdStreamPlan& plan, int H, int W, hipStream_t st);   // builds and uploads unless the plan already is for (H, W); may synchronise st
+// the schedule alone (host arithmetic, no GPU): chunks[0..3] = header, then { column tile, S, E, passes } per chunk; returns the passes of the launch
+unsigned ahd_stream_chunks(int H, int W, int slots_per_xcd, std::vector<int4>& chunks, unsigned first[8], unsigned count[8]);
 void ahd_stream_plan_free(AhdStreamPlan& plan);
 bool ahd_stream_ok(int H, int W, int hdr, const void* d_lablut, int lab_planes);
 // k_ahd.hip: tail = colour tail of devmath.h (0 none, 1 lin sRGB, 2 sRGB, 3 Reinhard + sRGB);

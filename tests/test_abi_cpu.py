@@ -324,3 +324,42 @@ def test_bench_verify_helpers_and_cpu_team_report(monkeypatch):
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
     n, why = oracle._team()
     assert n == 16 and "256 cores visible" in why
+
+
+def test_streaming_select_schedule_tiles_every_column_once():
+    """pysp_ahd_stream_chunks (the work partition of the streaming select kernel, host arithmetic): for a range of frame sizes and queue widths the chunks of
+    every 14-quad-wide column cover its quad rows 0 .. h-1 exactly once, in order; XCD x's queue is a contiguous range of columns; a chunk is a head pass plus
+    `passes - 1` chained ones, counted exactly as the kernel's loop runs them (head: rows S+1 .. S+14; every further pass 16 rows; a pass more when the last
+    row is the stashed one); chunk lengths are 14 + 16 m with m <= 7 except at the bottom of a column; and the queues drain from long chunks to short ones."""
+    import ctypes
+    from pysp_amd import _lib
+    L = _lib.lib()
+    for (H, W, slots) in ((8, 8, 192), (28, 28, 192), (120, 176, 192), (4000, 6000, 192), (4000, 6000, 224), (8736, 11648, 192), (2184, 2912, 4), (600, 60, 1)):
+        first, count = (ctypes.c_uint * 8)(), (ctypes.c_uint * 8)()
+        n = L.pysp_ahd_stream_chunks(H, W, slots, None, 0, first, count)
+        assert n > 0
+        buf = (ctypes.c_int * (4 * n))()
+        assert L.pysp_ahd_stream_chunks(H, W, slots, buf, n, first, count) == n
+        ch = np.frombuffer(buf, dtype=np.int32).reshape(n, 4)
+        h, w = H // 2, W // 2
+        ncols = (w + 13) // 14
+        assert sum(count) == n and list(first) == [sum(count[:x]) for x in range(8)]
+        for x in range(8):
+            q = ch[first[x]:first[x] + count[x]]
+            c0, c1 = ncols * x // 8, ncols * (x + 1) // 8
+            assert sorted(set(q[:, 0].tolist())) == list(range(c0, c1))
+            assert (np.diff(q[:, 0]) >= 0).all()                                    # column by column
+            lens = q[:, 2] - q[:, 1]
+            if len(q) > 8 and h > 200:
+                assert lens[:4].min() >= lens[-4:].max()                           # guided schedule: the long chunks first
+        for c in range(ncols):
+            rows = ch[ch[:, 0] == c]
+            assert rows[0, 1] == -1 and rows[-1, 2] == h - 1
+            assert (rows[1:, 1] == rows[:-1, 2]).all()                             # S of a chunk = E of the one above: rows S+1 .. E, no gap, no overlap
+            for (_c, S, E, passes) in rows:
+                ln = E - S
+                assert ln >= 1 and (E == h - 1 or ((ln - 14) % 16 == 0 and 0 <= (ln - 14) // 16 <= 7))
+                q0, npass = S, 1
+                while q0 + 15 <= E:                                                 # the kernel's loop (k_ahd_select_stream)
+                    q0 += 16; npass += 1
+                assert npass == passes and q0 + 14 >= E
