@@ -103,3 +103,31 @@ def test_select_ties_go_vertical(orc):
     out, taps = orc.demosaic_ahd(bay, np.ones(3, np.float32), M, False, 0, taps=True)
     assert np.array_equal(taps["map_h"], taps["map_v"]) and (taps["map_h"] == 9).all()
     assert np.array_equal(out[..., 1], taps["g_v"])
+
+
+def test_warp_phase_check_on_the_oracle_itself(orc):
+    """oracle/checks.py::warp_phase_check (the classified bar of the warp tests and bench lines), on CPU: the oracle's own warp passes with nothing differing, also on
+    a band of rows and with a prior; a value moved by one float32 ULP far from any phase boundary fails; a value replaced by the interpolation at the NEIGHBOURING
+    phase passes only where the coordinate really lies within 2 ULP of a 1/32-px boundary."""
+    from oracle.checks import _near_boundary, warp_phase_check
+    rng = np.random.default_rng(2)
+    H, W = 70, 96
+    img = rng.random((H, W, 3), dtype=np.float32)
+    co = np.array([[1.0, 0.02, 0.004, 0.0, 0.001, 0.0], [1.0, 0.0, 0.0, 0.0, 0.0, 0.0], [0.99, -0.02, 0.004, 0.0, 0.0, 0.001]])
+    ref = orc.warp_rectilinear(img, co, (0.5, 0.45))
+    st = warp_phase_check(ref, img, co, (0.5, 0.45))
+    assert st["differing"] == 0 and st["values"] == H * W * 3
+    assert warp_phase_check(ref[20:40], img, co, (0.5, 0.45), rows=(20, 40))["differing"] == 0
+    bad = ref.copy()
+    t = orc.warp_table(*[float(np.float32(v)) for v in co[0]], W, H, 0.5, 0.45, 1.0)
+    far = ~(_near_boundary(np.ascontiguousarray(t[..., 0]), W - 1) | _near_boundary(np.ascontiguousarray(t[..., 1]), H - 1))
+    y, x = np.argwhere(far)[len(np.argwhere(far)) // 2]
+    bad[y, x, 0] = np.nextafter(bad[y, x, 0], np.float32(2))
+    with pytest.raises(AssertionError, match="more than 2 ULP"):
+        warp_phase_check(bad, img, co, (0.5, 0.45))
+    # row-band tables and the n-pixel remap agree with the whole-frame forms
+    assert np.array_equal(orc.warp_table(1.0, 0.02, 0.004, 0.0, 0.001, 0.0, W, H, 0.5, 0.45, 1.0, rows=(10, 30)), t[10:30])
+    mx, my = np.clip(t[..., 0], 0, W - 1), np.clip(t[..., 1], 0, H - 1)
+    whole = orc.remap_lanczos4(np.ascontiguousarray(img[..., 0]), mx, my)
+    assert np.array_equal(orc.remap_lanczos4(np.ascontiguousarray(img[..., 0]), mx[10:30], my[10:30]), whole[10:30])
+    assert np.array_equal(orc.remap_lanczos4(np.ascontiguousarray(img[..., 0]), mx.ravel()[5:77], my.ravel()[5:77]), whole.ravel()[5:77])
