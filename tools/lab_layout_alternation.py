@@ -32,26 +32,41 @@ def measure(size=(4000, 6000), frames=1200, periods=(1, 4, 16, 64, 300)):
     rows = []
     for period in periods:
         row = {"period": period}
-        for layout in ("auto", "packed", "planes"):
-            ctx = _lib.Context(0)
-            ctx.set_kernel_timing(0)
-            ctx.set_lab_layout(layout)
+        layouts = ("auto", "packed", "planes")
+        ctxs, pos, spent = {}, {}, {}
+        for layout in layouts:
+            ctxs[layout] = _lib.Context(0)
+            ctxs[layout].set_kernel_timing(0)
+            ctxs[layout].set_lab_layout(layout)
+            pos[layout], spent[layout] = 0, 0.0
 
-            def run(n):
-                for i in range(n):
-                    src = (scene if (i // period) % 2 == 0 else noise)[i % 2]
-                    _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(src.data_ptr()), H, W, wb, M, 2, 0, 1, 2, ctypes.c_void_p(out.data_ptr())))
-                    if i % 256 == 255:
-                        ctx.sync()                      # keep the launch queue bounded (the policy still sees the host hundreds of frames ahead)
-            run(max(64, 2 * period))                    # warm up: clocks, and the policy's first decisions
-            ctx.sync(); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(frames)
-            ctx.sync()
-            row[layout] = (time.perf_counter() - t0) / frames * 1e3
-            del ctx
+        def run(layout, n):
+            ctx, i0 = ctxs[layout], pos[layout]
+            for i in range(i0, i0 + n):                 # the stream goes on where this layout's last slice ended
+                src = (scene if (i // period) % 2 == 0 else noise)[i % 2]
+                _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(src.data_ptr()), H, W, wb, M, 2, 0, 1, 2, ctypes.c_void_p(out.data_ptr())))
+                if i % 256 == 255:
+                    ctx.sync()                          # keep the launch queue bounded (the policy still sees the host hundreds of frames ahead)
+            pos[layout] = i0 + n
+        for layout in layouts:
+            run(layout, max(64, 2 * period))            # warm up: clocks, and the policy's first decisions
+            ctxs[layout].sync()
+        torch.cuda.synchronize()
+        # the three layouts take turns in slices (whole alternation cycles), so that clock and temperature drift of the box hits all of them alike
+        slices = 3
+        per = max(2 * period, (frames // slices) // (2 * period) * (2 * period))
+        for rep in range(slices):
+            for layout in (layouts if rep % 2 == 0 else layouts[::-1]):
+                t0 = time.perf_counter()
+                run(layout, per)
+                ctxs[layout].sync()
+                spent[layout] += time.perf_counter() - t0
+        for layout in layouts:
+            row[layout] = spent[layout] / (slices * per) * 1e3
+        row["frames_per_layout"] = slices * per
         row["auto_over_best_fixed"] = row["auto"] / min(row["packed"], row["planes"])
         rows.append(row)
+        ctxs.clear()
     return rows
 
 
@@ -62,7 +77,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     H, W = (int(v) for v in a.size.lower().split("x"))
     rows = measure((H, W), a.frames)
-    print("# scene / noise alternation, %dx%d, %d frames per cell, ms per frame (AHD + colour tail, device resident)" % (H, W, a.frames))
+    print("# scene / noise alternation, %dx%d, about %d frames per cell in three interleaved slices, ms per frame (AHD + colour tail, device resident)" % (H, W, a.frames))
     print("| period | auto | packed | planes | auto / better fixed layout |\n|---|---|---|---|---|")
     for r in rows:
         print("| %d | %.4f | %.4f | %.4f | %.3f |" % (r["period"], r["auto"], r["packed"], r["planes"], r["auto_over_best_fixed"]))
