@@ -140,8 +140,12 @@ class _OraclePipe:
     def sync(self):
         pass
 
-    def demosaic(self, bayer, wb, M, quality, hdr, stages):
-        return self.torch.from_numpy(self.orc.demosaic_ahd(bayer.numpy(), wb, M, hdr, stages))
+    def demosaic(self, bayer, wb, M, quality, hdr, stages, out=None):
+        res = self.torch.from_numpy(self.orc.demosaic_ahd(bayer.numpy(), wb, M, hdr, stages))
+        if out is None:
+            return res
+        out.copy_(res)            # halo rows included, as the device kernels write them (multi_gpu: the exchange overwrites the ones the warp reads)
+        return out
 
     def _cells(self, H, W, coeffs, centre, scale):
         rows = []
