@@ -9,6 +9,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -50,6 +52,58 @@ bool host_is_pinned(const void* p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
+
+// The caller pages this library has page-locked for the duration of a host call (run_pipeline_host_t), process-wide: two calls may hold the SAME mosaic at the
+// same time (two contexts on two threads, one frame at two qualities), and the first to return must not unlock pages the other's DMA is still reading.
+//   acquire: 2 = [p, p + n) is locked by this book and stays locked until release() (the range lies inside one entry: a reference is taken; or it overlaps
+//                none and hipHostRegister succeeded), 1 = locked by somebody else (the caller's own hipHostRegister / hipHostMalloc: theirs to keep alive),
+//                0 = pageable (registration not wanted, or refused by the runtime).
+// A range that overlaps an entry only PARTLY (overlapping views of one array on two threads) waits for that entry's release: a half-locked range is neither
+// a valid asynchronous source nor registrable.  A call holds at most one entry and takes it before anything else, so the wait cannot cycle.
+struct HostPins {
+    struct Entry { uintptr_t lo, hi; int refs; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Entry> v;
+    int acquire(const void* p, size_t n, bool may_register, double* register_ms) {
+        const uintptr_t lo = (uintptr_t)p, hi = lo + n;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            bool partial = false;
+            for (auto& e : v) {
+                if (e.lo <= lo && hi <= e.hi) { e.refs++; return 2; }
+                if (e.lo < hi && lo < e.hi) partial = true;
+            }
+            if (!partial) break;
+            cv.wait(lk);
+        }
+        if (host_is_pinned(p)) return 1;
+        if (!may_register) return 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        void* const base = const_cast<void*>(p);
+        bool ok = hipHostRegister(base, n, hipHostRegisterDefault) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); ok = hipHostRegister(base, n, hipHostRegisterReadOnly) == hipSuccess; }      // (a read-only mapping)
+        if (!ok) (void)hipGetLastError();
+        if (register_ms) *register_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (!ok) return 0;
+        v.push_back({lo, hi, 1});
+        return 2;
+    }
+    void release(const void* p, size_t n) {
+        const uintptr_t lo = (uintptr_t)p, hi = lo + n;
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i].lo <= lo && hi <= v[i].hi) {
+                if (--v[i].refs == 0) {
+                    hipError_t e = hipHostUnregister((void*)v[i].lo); (void)e;
+                    v.erase(v.begin() + i);
+                    cv.notify_all();
+                }
+                return;
+            }
+    }
+};
+HostPins& host_pins() { static HostPins* b = new HostPins; return *b; }      // (never destroyed: a call may still be running on another thread at exit)
 
 // even, >= 2 and <= 2^20 per side: the kernels form tile-local byte offsets with 24-bit multiplies (row * W * 12 bytes), and no sensor is near that
 bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && H <= (1 << 20) && W <= (1 << 20); }
@@ -798,14 +852,15 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     static const int h2d_register_env = [] { const char* e = getenv("PYSP_H2D_REGISTER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();     // 1 / 0: always / never page-lock the caller's mosaic for the call
     static const bool d2h_sync = [] { const char* e = getenv("PYSP_D2H_SYNC"); return e && e[0] == '1'; }();             // experiment: helper thread downloads with the blocking hipMemcpy
     struct Registered {
-        void* p = nullptr;
+        const void* p = nullptr;
+        size_t n = 0;
         pysp_ctx* c = nullptr;
         ~Registered() {
             if (!p) return;
-            // every return path: no DMA may still read the pages when they are unlocked (the regular path has drained the streams already: these waits cost nothing there)
+            // every return path: no DMA of THIS call may still read the pages when its reference goes (the regular path has drained the streams already: these waits cost nothing there)
             hipError_t e = hipStreamSynchronize(c->up_stream); (void)e;
             e = hipStreamSynchronize(c->stream); (void)e;
-            e = hipHostUnregister(p); (void)e;
+            host_pins().release(p, n);
         }
     } reg;
     reg.c = ctx;
@@ -813,25 +868,19 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     // form: 0.53 ms per band instead of 0.12, 8.7 ms per 24 MP frame) or, issued from a second thread, lands on the downloads' DMA engine every other call
     // (helper-thread form: 5.8 / 7.0 ms, bimodal -- rounds 2-4's unexplained "pinned result is slower").  So the caller's mosaic is page-locked for the duration
     // of the call (hipHostRegister: 0.27 ms for 96 MB the first time, measured; the pages are the caller's, nothing is copied) and every transfer of the call is a
-    // plain asynchronous DMA: 5.9 ms, every call (profiles/r5_dropin_probe.log).  A mosaic that cannot be registered (already registered by someone else,
-    // read-only mapping the driver refuses) keeps the helper-thread form.
+    // plain asynchronous DMA: 5.9 ms, every call (profiles/r5_dropin_probe.log).  A mosaic that cannot be registered (a mapping the driver refuses) keeps the
+    // helper-thread form.  The lock is taken through the process-wide book above (HostPins): concurrent calls on one mosaic share it.
     const bool out_pinned = host_is_pinned(out);
     const bool want_register = h2d_register_env == 1 || (h2d_register_env < 0 && out_pinned && !pipe_env);
-    if (want_register && !host_is_pinned(bayer)) {
-        const auto t0 = clk::now();
-        void* const base = const_cast<T*>(bayer);
-        if (hipHostRegister(base, px * sizeof(T), hipHostRegisterDefault) == hipSuccess) reg.p = base;
-        else {
-            (void)hipGetLastError();
-            if (hipHostRegister(base, px * sizeof(T), hipHostRegisterReadOnly) == hipSuccess) reg.p = base; else (void)hipGetLastError();
-        }
-        if (trace) fprintf(stderr, "[pysp band trace] hipHostRegister %.2f ms (%s)\n", std::chrono::duration<double, std::milli>(clk::now() - t0).count(), reg.p ? "ok" : "failed");
-    }
+    double reg_ms = -1.0;
+    const int in_pin = host_pins().acquire(bayer, px * sizeof(T), want_register, &reg_ms);      // 2: ours for the call, 1: the caller's own, 0: pageable
+    if (in_pin == 2) { reg.p = bayer; reg.n = px * sizeof(T); }
+    if (trace && want_register) fprintf(stderr, "[pysp band trace] mosaic %s (hipHostRegister %.2f ms)\n", in_pin == 2 ? "page-locked for the call" : in_pin == 1 ? "page-locked by the caller" : "pageable", reg_ms);
     static const bool d2h_kernel = [] { const char* e = getenv("PYSP_D2H_KERNEL"); return e && e[0] == '1'; }();
     static const int pipe_events = [] { const char* e = getenv("PYSP_HOST_PIPE"); return e && !strcmp(e, "events") ? 1 : 0; }();
     // (a pageable mosaic keeps the helper-thread form: next to queued asynchronous downloads the runtime's blocking pageable upload takes 0.53 ms per band
     // instead of 0.12 -- 8.7 ms per frame, profiles/r5_dropin_probe.log -- unless the mosaic was page-locked for the call, PYSP_H2D_REGISTER=1)
-    if (!pipe_env && out_pinned && (pipe_events || reg.p || host_is_pinned(bayer))) {
+    if (!pipe_env && out_pinned && (pipe_events || in_pin)) {
         std::vector<double> tr;
         int rc = PYSP_OK;
         for (int b = 0; b < nb && rc == PYSP_OK; b++) {

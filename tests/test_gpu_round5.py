@@ -203,6 +203,52 @@ def test_deferred_recipe_equals_eager_recipe(orc, wbobj):
         pysp_amd.set_lazy(True)
 
 
+def test_concurrent_host_calls_share_one_page_locked_mosaic(orc):
+    """The fused host call page-locks the caller's mosaic for its duration (hipHostRegister); the lock is kept in a process-wide book so that two calls
+    holding the SAME mosaic at once -- two contexts on two threads, here at two qualities -- or OVERLAPPING views of one array never unlock (or half-lock)
+    pages another call's DMA is reading.  Every result of every round must be the bits of the call run alone."""
+    import ctypes
+    import threading
+    from pysp_amd import _lib
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    L = _lib.lib()
+    H, W = 4608, 2048                                     # every view > 4 MP: banded, asynchronous transfers
+    bay = rggb_frame(H, W, 77)
+    wbc, Mc = _lib.wb3(wb), _lib.mat9(M)
+    # (view rows, quality): the whole frame twice, and two views that overlap in 256 rows
+    jobs = [((0, H), 2), ((0, H), 1), ((0, H // 2 + 128), 1), ((H // 2 - 128, H), 2)]
+    ctxs = [_lib.Context(0) for _ in jobs]
+    outs = [_lib.empty_f32((r1 - r0, W, 3)) for (r0, r1), _ in jobs]
+    want = []
+    for ((r0, r1), q), c, o in zip(jobs, ctxs, outs):      # alone, one after the other
+        _lib.check(L.pysp_pipeline_srgb_f32(c.handle, _lib.ptr(bay[r0:r1]), r1 - r0, W, wbc, Mc, q, 0, 1, 0, _lib.ptr(o)))
+        want.append(o.copy())
+    assert np.array_equal(want[0], orc.pipeline_srgb(bay, wb, M, 2, False, 1, False))
+    errs = []
+    go = threading.Barrier(len(jobs))
+
+    def run(k):
+        (r0, r1), q = jobs[k]
+        try:
+            for it in range(6):
+                go.wait(timeout=120)
+                outs[k][:] = 0
+                _lib.check(L.pysp_pipeline_srgb_f32(ctxs[k].handle, _lib.ptr(bay[r0:r1]), r1 - r0, W, wbc, Mc, q, 0, 1, 0, _lib.ptr(outs[k])))
+                if not np.array_equal(outs[k], want[k]):
+                    errs.append((k, it, int((outs[k] != want[k]).sum())))
+        except Exception as e:                              # noqa: BLE001  (reported below, on the main thread)
+            errs.append((k, repr(e)))
+            go.abort()
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(len(jobs))]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=600)
+    assert not errs, errs
+    # afterwards nothing of the mosaic is left page-locked by the library: the next call registers it afresh and still gets the same bits
+    _lib.check(L.pysp_pipeline_srgb_f32(ctxs[0].handle, _lib.ptr(bay), H, W, wbc, Mc, 2, 0, 1, 0, _lib.ptr(outs[0])))
+    assert np.array_equal(outs[0], want[0])
+
+
 def test_fusion_keeps_an_exposure_whose_lazy_image_was_read_elsewhere(orc, wbobj):
     """an exposure may hold a DeviceArray whose device copy another holder has released (np.asarray on the shared lazy result moves it to the
     host).  is_valid() counted such an exposure as empty and fuse_exposures_from_debayer dropped it silently; it still resolves through .image and is fused."""
