@@ -216,14 +216,18 @@ class DeferredImage(DeviceArray):
                     dptr = _lib.lib().pysp_dev_alloc(self._ctx.handle, ctypes.c_size_t(self.nbytes))
                     if not dptr:
                         raise MemoryError(_lib.last_error())
+                    try:
+                        if tail == 0:
+                            _lib.check(_lib.lib().pysp_demosaic_dev(self._ctx.handle, src.ptr, H, W, wb, M, q, hdr, st, ctypes.c_void_p(int(dptr))))
+                        else:
+                            _lib.check(_lib.lib().pysp_pipeline_dev(self._ctx.handle, src.ptr, H, W, wb, M, q, hdr, st, tail, ctypes.c_void_p(int(dptr))))
+                    except Exception:
+                        _lib.lib().pysp_dev_free(self._ctx.handle, ctypes.c_void_p(int(dptr)))       # still pending: the next reader tries again (or sees the same error)
+                        raise
+                    finally:
+                        src.release()
                     self._ptr = int(dptr)
-                    call = _lib.lib().pysp_demosaic_dev if tail == 0 else None
-                    if call is not None:
-                        _lib.check(call(self._ctx.handle, src.ptr, H, W, wb, M, q, hdr, st, ctypes.c_void_p(self._ptr)))
-                    else:
-                        _lib.check(_lib.lib().pysp_pipeline_dev(self._ctx.handle, src.ptr, H, W, wb, M, q, hdr, st, tail, ctypes.c_void_p(self._ptr)))
                     self._keepalive = self._plan["mosaic"]
-                    src.release()
                     self._plan = None
         return super().ptr
 
@@ -236,8 +240,7 @@ class DeferredImage(DeviceArray):
                     _lib.check(_lib.lib().pysp_pipeline_f32(self._ctx.handle, _lib.ptr(self._plan["mosaic"]), H, W, wb, M, q, hdr, st, tail, _lib.ptr(out)))
                     self._host = out
                     self._plan = None
-            return self._host
-        return super().numpy()
+        return self._host if self._host is not None else super().numpy()       # (realised on the device by another reader in the meantime: the ordinary download)
 
     def release(self) -> None:
         self._plan = None
