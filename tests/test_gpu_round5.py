@@ -249,6 +249,88 @@ def test_concurrent_host_calls_share_one_page_locked_mosaic(orc):
     assert np.array_equal(outs[0], want[0])
 
 
+def test_frame_whose_result_exceeds_4_GiB(orc):
+    """Maximum sizes: a 19 000 x 19 000 mosaic (361 MP; the float32 RGB result is 4.33 GB, its byte offsets pass 2^31 and 2^32, its element offsets 2^30)
+    through Draft, EAG and AHD (one median stage, sRGB tail) and the stand-alone colour calls on the device; crops at the frame's corners, in the middle
+    and at the rows where the result's byte offset crosses 2^31 and 2^32 against the oracle, bit for bit (crop interior: 24 px of margin unless the crop
+    touches a true border).  The mosaic is generated on the device; only crops travel."""
+    import torch
+    from pysp_amd import _lib
+    from pysp_amd.pipeline import DevicePipeline
+    wb, M = _wbM(orc)
+    H = W = 19000
+    pipe = DevicePipeline(0)
+    g = torch.Generator(device="cuda"); g.manual_seed(4242)
+    bay = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    for r0 in range(0, H, 1000):                           # in slabs: smooth ramps x noise, so that AHD's two directions both win somewhere
+        rows = torch.arange(r0, min(H, r0 + 1000), device="cuda", dtype=torch.float32)[:, None]
+        cols = torch.arange(W, device="cuda", dtype=torch.float32)[None, :]
+        base = 0.3 + 0.25 * torch.sin(rows * (2 * np.pi / 131)) * torch.cos(cols * (2 * np.pi / 257))
+        bay[r0:r0 + 1000] = (base + 0.2 * torch.rand((rows.shape[0], W), generator=g, device="cuda")).clamp_(0, 1)
+    row_2g, row_4g = (1 << 31) // (W * 12), (1 << 32) // (W * 12)
+    sites = [(0, 0), (0, W - 96), (H - 96, 0), (H - 96, W - 96), (H // 2 - 48, W // 2 - 48), (row_2g - 48, 0), (row_2g - 48, W - 96), (row_4g - 48, 4000), (row_4g - 48, W - 96)]
+    out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    for q, stages, tail, ref in ((0, 0, 0, lambda c: orc.demosaic_draft(c, wb)), (1, 0, 0, lambda c: orc.demosaic_eag(c, wb)),
+                                 (2, 1, 2, lambda c: orc.pipeline_srgb(c, wb, M, 2, False, 1, False))):
+        out.fill_(-7.0)
+        if tail == 2:
+            pipe.demosaic_to_srgb(bay, wb, M, q, False, stages, False, out=out)
+        else:
+            pipe.demosaic(bay, wb, M, q, False, stages, out=out)
+        pipe.sync()
+        assert float(out[-1, -1, 2]) != -7.0 and float(out[row_4g + 1, 5, 0]) != -7.0
+        for (y0, x0) in sites:
+            y0 -= y0 & 1; x0 -= x0 & 1
+            crop = bay[y0:y0 + 96, x0:x0 + 96].cpu().numpy()
+            want = ref(np.ascontiguousarray(crop))
+            got = out[y0:y0 + 96, x0:x0 + 96].cpu().numpy()
+            m = 24
+            ys = slice(0 if y0 == 0 else m, 96 if y0 + 96 == H else 96 - m)
+            xs = slice(0 if x0 == 0 else m, 96 if x0 + 96 == W else 96 - m)
+            assert np.array_equal(got[ys, xs], want[ys, xs]), (q, y0, x0)
+    # the uint16 loader (bayer_normalize fused into the tile loader) on the same geometry
+    raw = (bay * 16000.0).to(torch.int32).to(torch.int16)                   # values < 2^15: the int16 view of uint16 data
+    black, sat = np.array([256, 260, 250, 258], np.float32), np.array([15000, 15100, 14900, 15050], np.float32)
+    pipe.raw_u16_to_rgb(raw, black, sat, wb, M, 2, 1, 2, out=out); pipe.sync()
+    for (y0, x0) in sites[3:]:
+        y0 -= y0 & 1; x0 -= x0 & 1
+        crop = raw[y0:y0 + 96, x0:x0 + 96].cpu().numpy().view(np.uint16)
+        want = orc.pipeline_srgb(orc.bayer_normalize(np.ascontiguousarray(crop), black, sat), wb, M, 2, False, 1, False)
+        got = out[y0:y0 + 96, x0:x0 + 96].cpu().numpy()
+        ys = slice(24, 96 if y0 + 96 == H else 72); xs = slice(0 if x0 == 0 else 24, 96 if x0 + 96 == W else 72)
+        assert np.array_equal(got[ys, xs], want[ys, xs]), ("u16", y0, x0)
+    del raw
+    # config 5's chain at this size: AHD with three median stages, then WarpRectilinear (Lanczos-4 over a 4.33 GB source) under the classified bar, on the
+    # output rows around the 2^31 / 2^32 byte marks and the frame's last rows
+    from oracle.checks import warp_phase_check
+    pipe.demosaic(bay, wb, M, 2, False, 3, out=out); pipe.sync()
+    y0, x0 = (row_4g - 48) & ~1, 4000                                       # (even: the crop keeps the CFA phase)
+    want = orc.demosaic_ahd(np.ascontiguousarray(bay[y0:y0 + 128, x0:x0 + 128].cpu().numpy()), wb, M, False, 3)
+    assert np.array_equal(out[y0 + 40:y0 + 88, x0 + 40:x0 + 88].cpu().numpy(), want[40:88, 40:88])
+    coeffs = np.array([[1.0, 0.01, 0.002, 0, 0, 0], [1.0, 0, 0, 0, 0, 0], [1.0, -0.01, 0.002, 0, 0, 0]])
+    warped = torch.empty_like(out)
+    pipe.warp(out, coeffs, (0.5, 0.5), 1.0, out=warped); pipe.sync()
+    src_h = out.cpu().numpy()
+    for r in (row_2g - 2, row_4g - 2, H - 4):
+        res = warp_phase_check(warped[r:r + 4].cpu().numpy(), src_h, coeffs, (0.5, 0.5), 1.0, rows=(r, r + 4))
+        assert res["differing_outside_boundary_set"] == 0 and res["differing_not_a_neighbouring_phase"] == 0, (r, res)
+    del src_h, warped
+    # stand-alone colour calls on 1.08e9 values: cam_to_rgb (clip + float64 CCM) and lin_srgb_to_srgb over the whole buffer, sampled at its ends and at 2^31 / 2^32 bytes
+    pipe.demosaic(bay, wb, M, 1, False, 0, out=out); pipe.sync()
+    import ctypes
+    L = _lib.lib()
+    lin, srgb = torch.empty_like(out), torch.empty_like(out)
+    dp = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(L.pysp_cam_to_rgb_dev(pipe.ctx.handle, dp(out), ctypes.c_size_t(H * W), _lib.mat9(M), 1, dp(lin)))
+    _lib.check(L.pysp_lin_srgb_to_srgb_dev(pipe.ctx.handle, dp(lin), ctypes.c_size_t(H * W * 3), dp(srgb)))
+    pipe.sync()
+    for r in (0, row_2g, row_4g, H - 1):
+        cam = out[r].cpu().numpy()
+        want_lin = orc.cam_to_rgb(cam, M, True)
+        assert np.array_equal(lin[r].cpu().numpy(), want_lin), r
+        assert np.array_equal(srgb[r].cpu().numpy(), orc.lin_srgb_to_srgb(want_lin)), r
+
+
 def test_fusion_keeps_an_exposure_whose_lazy_image_was_read_elsewhere(orc, wbobj):
     """an exposure may hold a DeviceArray whose device copy another holder has released (np.asarray on the shared lazy result moves it to the
     host).  is_valid() counted such an exposure as empty and fuse_exposures_from_debayer dropped it silently; it still resolves through .image and is fused."""
