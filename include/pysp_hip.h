@@ -206,6 +206,16 @@ int pysp_pipeline_srgb_f32(pysp_ctx *ctx, const float *bayer, int H, int W, cons
  * demosaic() -> to_lin_srgb() [-> lin_srgb_to_srgb()] into -- one upload overlapped with the kernels and the download, in bands. */
 int pysp_pipeline_f32(pysp_ctx *ctx, const float *bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail, float *out);
 int pysp_pipeline_srgb_dev(pysp_ctx *ctx, const float *d_bayer, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int reinhard, float *d_srgb);
+/* n_frames HOST mosaics of one geometry and one set of camera parameters -> n_frames host results (BASELINE config 3's frames as they arrive from a decoder;
+ * the loop `for raw in frames: raw.demosaic(q).to_lin_srgb()` of README.md:55-63) through ONE band chain: frame k+1's bands are uploaded and computed while
+ * frame k's are still on their way down, so a stream of frames costs its downloads plus one band instead of upload + download + drain per call.  The
+ * asynchronous form needs every result page-locked (pysp_host_alloc / hipHostMalloc / hipHostRegister) and every mosaic page-locked or lockable for the
+ * call; anything else is processed frame by frame (pysp_pipeline_f32 n times).  Same bits as n single calls either way.  The u16 form takes sensor data
+ * (normalization.py:4-24 fused into the loader, as pysp_pipeline_u16_f32). */
+int pysp_pipeline_batch_f32(pysp_ctx *ctx, const float *const *bayers, int n_frames, int H, int W, const float wb[3], const double M[9], int quality, int hdr, int stages, int tail,
+                            float *const *outs);
+int pysp_pipeline_batch_u16_f32(pysp_ctx *ctx, const uint16_t *const *bayers, int n_frames, int H, int W, const float black[4], const float sat[4], const float wb[3],
+                                const double M[9], int quality, int hdr, int stages, int tail, float *const *outs);
 
 /* General form: tail 0 = pysp_demosaic_dev, 1 = + to_lin_srgb (clip + CCM; BASELINE config 3 "debayer + WB + CCM"),
  * 2 = pysp_pipeline_srgb_dev, 3 = with x/(1+x) in between. */

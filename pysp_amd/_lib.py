@@ -83,6 +83,8 @@ _SIGNATURES = {
     "pysp_pipeline_dev": (_int, [_vp, _vp, _int, _int, _f32p, _f64p, _int, _int, _int, _int, _vp]),
     "pysp_pipeline_batch_dev": (_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _int, _int, _int, _f32p, _f64p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p)]),
     "pysp_pipeline_u16_f32": (_int, [_vp, _vp, _int, _int, _f32p, _f32p, _f32p, _f64p, _int, _int, _int, _int, _vp]),
+    "pysp_pipeline_batch_f32": (_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _int, _int, _int, _f32p, _f64p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pysp_pipeline_batch_u16_f32": (_int, [_vp, ctypes.POINTER(ctypes.c_void_p), _int, _int, _int, _f32p, _f32p, _f32p, _f64p, _int, _int, _int, _int, ctypes.POINTER(ctypes.c_void_p)]),
     "pysp_pipeline_u16_dev": (_int, [_vp, _vp, _int, _int, _f32p, _f32p, _f32p, _f64p, _int, _int, _int, _int, _vp]),
     "pysp_fuse_raw_f32": (_int, [_vp, ctypes.POINTER(_vp), _int, _int, _int, _f32p, _f32p, _int, _vp, _vp]),
     "pysp_fuse_raw_dev": (_int, [_vp, ctypes.POINTER(_vp), _int, _int, _int, _f32p, _f32p, _int, _vp, _vp]),

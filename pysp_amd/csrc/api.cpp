@@ -156,6 +156,8 @@ struct pysp_ctx {
     // banded host pipeline: a second stream for the device-to-host leg and per-buffer events
     hipStream_t copy_stream = nullptr, up_stream = nullptr;
     hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_up[2] = {nullptr, nullptr};
+    static constexpr int RING = 16;
+    hipEvent_t ev_ring[RING] = {};            // host batch: band g's download has finished (the host stays at most a few bands ahead of the device)
     // device buffers handed to callers that keep images on the GPU between calls (pysp_dev_alloc): freed blocks are cached
     struct Block { void* p; size_t cap; bool used; };
     std::vector<Block> blocks;
@@ -353,6 +355,7 @@ void pysp_ctx_destroy(pysp_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->ev_done[i]) { e = hipEventDestroy(c->ev_done[i]); (void)e; }
     for (int i = 0; i < 2; i++) if (c->ev_free[i]) { e = hipEventDestroy(c->ev_free[i]); (void)e; }
     for (int i = 0; i < 2; i++) if (c->ev_up[i]) { e = hipEventDestroy(c->ev_up[i]); (void)e; }
+    for (int i = 0; i < pysp_ctx::RING; i++) if (c->ev_ring[i]) { e = hipEventDestroy(c->ev_ring[i]); (void)e; }
     for (auto& pl : c->plans) ahd_stream_plan_free(pl);
     if (c->lanczos) { e = hipFree(c->lanczos); (void)e; }
     if (c->labtab) { e = hipFree(c->labtab); (void)e; }
@@ -1057,6 +1060,122 @@ int pysp_pipeline_u16_f32(pysp_ctx* ctx, const uint16_t* bayer, int H, int W, co
     if (!bayer || !out || !black || !sat) return fail(PYSP_EBADARG, "pipeline_u16: null pointer");
     if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_u16: tail must be 0..3");
     return run_pipeline_host_t<uint16_t>(ctx, bayer, black, sat, H, W, wb, M, quality, hdr, stages, tail, out);
+}
+
+// A batch of host-resident frames of one geometry through ONE band chain (round 5): the bands of frame k+1 are uploaded and computed while frame k's last
+// bands are still on their way down, so that a stream of frames costs its downloads (288 MB per 24 MP frame at the link's 57 GB/s: 5.05 ms) plus one band,
+// instead of upload-of-the-first-band + downloads + drain per call.  Takes the asynchronous form only (every result page-locked, every mosaic page-locked or
+// lockable through the book above); anything else runs frame by frame through run_pipeline_host_t -- same bits either way (a band's kernels see the band and
+// its halo rows exactly as in the single-frame call).
+extern "C++" template <typename T>
+static int run_pipeline_host_batch_t(pysp_ctx* ctx, const T* const* bayers, const float* black, const float* sat, int n, int H, int W, const float wb[3],
+                                     const double M[9], int quality, int hdr, int stages, int tail, float* const* outs) {
+    if (n < 0 || n > 65536) return fail(PYSP_EBADARG, "pipeline_batch: n_frames must be 0..65536 (got %d)", n);
+    if (n == 0) return PYSP_OK;
+    if (!bayers || !outs) return fail(PYSP_EBADARG, "pipeline_batch: null pointer table");
+    for (int f = 0; f < n; f++) if (!bayers[f] || !outs[f]) return fail(PYSP_EBADARG, "pipeline_batch: null pointer (frame %d)", f);
+    if (!even_dims(H, W)) return fail(PYSP_EBADARG, "demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
+    if (quality < PYSP_QUALITY_DRAFT || quality > PYSP_QUALITY_BEST) return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
+    const size_t px = (size_t)H * W;
+    static const bool serial_env = [] { const char* e = getenv("PYSP_HOST_BATCH"); return e && !strcmp(e, "serial"); }();      // A/B switch: frame by frame
+    struct Pins {
+        std::vector<std::pair<const void*, size_t>> held;
+        pysp_ctx* c = nullptr;
+        ~Pins() {
+            if (held.empty()) return;
+            if (c->up_stream) { hipError_t e = hipStreamSynchronize(c->up_stream); (void)e; }
+            if (c->copy_stream) { hipError_t e = hipStreamSynchronize(c->copy_stream); (void)e; }
+            hipError_t e = hipStreamSynchronize(c->stream); (void)e;
+            for (auto& h : held) host_pins().release(h.first, h.second);
+        }
+    } pins;
+    pins.c = ctx;
+    bool async_ok = !serial_env;
+    for (int f = 0; f < n && async_ok; f++) async_ok = host_is_pinned(outs[f]);
+    for (int f = 0; f < n && async_ok; f++) {
+        const int k = host_pins().acquire(bayers[f], px * sizeof(T), true, nullptr);
+        if (k == 2) pins.held.push_back({bayers[f], px * sizeof(T)});
+        if (k == 0) async_ok = false;
+    }
+    if (!async_ok) {
+        for (int f = 0; f < n; f++) TRY(run_pipeline_host_t<T>(ctx, bayers[f], black, sat, H, W, wb, M, quality, hdr, stages, tail, outs[f]));
+        return PYSP_OK;
+    }
+    const int st = stages < 0 ? 0 : stages;
+    const int halo = 8 + 4 * st;
+    static const int band_env = [] { const char* e = getenv("PYSP_BAND_ROWS"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 1) & ~1 : 0; }();
+    int band = band_env ? band_env : 256;
+    int nb = px < ((size_t)1 << 22) ? 1 : (H + band - 1) / band;      // small frames: one piece each, still chained frame to frame
+    if (nb < 2) { nb = 1; band = H; }
+    const int max_rows = (band + 2 * halo) < H ? (band + 2 * halo) : H;
+    T* d_in[2]; float* d_out[2];
+    for (int i = 0; i < 2; i++) {
+        RESERVE(ctx, i == 0 ? S_IN : S_IN2, (size_t)max_rows * W * sizeof(T), d_in[i]);
+        RESERVE(ctx, i == 0 ? S_OUT : S_OUT2, (size_t)max_rows * W * 12, d_out[i]);
+    }
+    if (quality == PYSP_QUALITY_BEST) {
+        void* t;
+        if (st >= 1) RESERVE(ctx, S_TMP0, (size_t)max_rows * W * 12, t);
+        if (st >= 2) RESERVE(ctx, S_TMP1, (size_t)max_rows * W * 12, t);
+    }
+    if (!ctx->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
+    }
+    auto mosaic = [&](const T* d) { return sizeof(T) == 2 ? mosaic_u16(reinterpret_cast<const uint16_t*>(d), black, sat) : mosaic_f32(reinterpret_cast<const float*>(d)); };
+    // The host runs ahead of the device by `depth` bands at most (default 2: it enqueues band g once band g-2 has landed; the two buffer pairs allow two bands
+    // in flight anyway, and band g's upload + kernels, 0.15 ms, fit inside band g-1's download, 0.32 ms).  Enqueueing further ahead makes this runtime SLOWER,
+    // not faster -- measured at 24 MP, 8 frames, ms per frame (tools/batch_probe.py): depth 2 / 3: 5.80, 4: 10.1, 8: 27.2, 16: 12.6, no limit: 16-24 -- while the
+    // single call (16 bands, no limit, one drain per frame) takes 5.93.  PYSP_BATCH_DEPTH overrides.
+    static const int depth_env = [] { const char* e = getenv("PYSP_BATCH_DEPTH"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > pysp_ctx::RING ? pysp_ctx::RING : v; }();
+    const int depth = depth_env ? depth_env : 2;
+    for (int i = 0; i < pysp_ctx::RING; i++) if (!ctx->ev_ring[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ring[i], hipEventDisableTiming));
+    static const bool btrace = [] { const char* e = getenv("PYSP_BAND_TRACE"); return e && e[0] == '1'; }();
+    const auto bt0 = std::chrono::steady_clock::now();
+    int rc = PYSP_OK;
+    long g = 0;                                                        // band number over the whole batch: the two buffer pairs alternate across frame borders
+    for (int f = 0; f < n && rc == PYSP_OK; f++) {
+        const T* const bayer = bayers[f];
+        float* const out = outs[f];
+        for (int b = 0; b < nb && rc == PYSP_OK; b++, g++) {
+            const int i = (int)(g & 1), y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
+            const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
+            if (g >= depth) HIP_TRY(hipEventSynchronize(ctx->ev_ring[(g - depth) % pysp_ctx::RING]));      // band g-depth has landed
+            if (g >= 2) HIP_TRY(hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0));      // d_in[i]: the kernels of band g-2 have read it
+            HIP_TRY(hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->up_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_up[i], ctx->up_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[i], 0));
+            if (g >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_free[i], 0));          // d_out[i]: band g-2 has left it
+            rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
+            if (rc != PYSP_OK) break;
+            HIP_TRY(hipEventRecord(ctx->ev_done[i], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0));
+            HIP_TRY(hipMemcpyAsync(out + (size_t)y0 * W * 3, d_out[i] + (size_t)(y0 - r0) * W * 3, (size_t)(y1 - y0) * W * 12, hipMemcpyDeviceToHost, ctx->copy_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_free[i], ctx->copy_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_ring[g % pysp_ctx::RING], ctx->copy_stream));
+        }
+        if (btrace) fprintf(stderr, "[pysp batch trace] frame %d enqueued at %.2f ms\n", f, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bt0).count());
+    }
+    hipError_t e = hipStreamSynchronize(ctx->copy_stream);             // (on an error above the enqueued work still drains here: the buffers belong to the context)
+    if (rc != PYSP_OK) return rc;
+    if (e != hipSuccess) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(e));
+    return pysp_ctx_sync(ctx);
+}
+int pysp_pipeline_batch_f32(pysp_ctx* ctx, const float* const* bayers, int n_frames, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
+                            int stages, int tail, float* const* outs) {
+    CTX_ENTER(ctx);
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_batch: tail must be 0..3");
+    return run_pipeline_host_batch_t<float>(ctx, bayers, nullptr, nullptr, n_frames, H, W, wb, M, quality, hdr, stages, tail, outs);
+}
+int pysp_pipeline_batch_u16_f32(pysp_ctx* ctx, const uint16_t* const* bayers, int n_frames, int H, int W, const float black[4], const float sat[4], const float wb[3],
+                                const double M[9], int quality, int hdr, int stages, int tail, float* const* outs) {
+    CTX_ENTER(ctx);
+    if (!black || !sat) return fail(PYSP_EBADARG, "pipeline_batch_u16: null pointer");
+    if (tail < 0 || tail > 3) return fail(PYSP_EBADARG, "pipeline_batch_u16: tail must be 0..3");
+    return run_pipeline_host_batch_t<uint16_t>(ctx, bayers, black, sat, n_frames, H, W, wb, M, quality, hdr, stages, tail, outs);
 }
 
 // ---- colour ---------------------------------------------------------------------------------------

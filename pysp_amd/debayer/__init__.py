@@ -56,3 +56,57 @@ def debayer_eag(image: RawRggbBayerData_BaseType) -> RawDemosaicData:
 def debayer_fast(image: RawRggbBayerData_BaseType) -> RawDemosaicData:
     """Draft demosaic: aligned quarter-resolution RGB, bilinear x2 (fast_resize.py:7-44)."""
     return _run(image, _lib.QUALITY_DRAFT)
+
+
+_BATCH_TAILS = {"image": 0, "lin_srgb": 1, "srgb": 2}
+
+
+def debayer_batch(images, quality, postprocess_stages: int = 1, to: str = "image"):
+    """A sequence of RawRggbBayerData of ONE geometry and ONE set of camera parameters through one banded transfer chain (pysp_pipeline_batch_f32): the loop
+    `[raw.demosaic(q, n).to_lin_srgb() for raw in frames]` of README.md:55-63 / BASELINE config 3 with frame k+1 uploaded and computed while frame k's result
+    is still on its way to the host.  Not part of the reference's API (which has no batch call); same bits as the loop.  `to`: "image" -> a list of
+    RawDemosaicData (what demosaic() returns), "lin_srgb" -> a list of float32 arrays (... .to_lin_srgb()), "srgb" -> (lin_srgb_to_srgb of that)."""
+    import ctypes
+    from ..const import QualityDemosaic
+    if to not in _BATCH_TAILS:
+        raise ValueError("to must be 'image', 'lin_srgb' or 'srgb'")
+    q = {QualityDemosaic.Draft: _lib.QUALITY_DRAFT, QualityDemosaic.Fast: _lib.QUALITY_FAST, QualityDemosaic.Best: _lib.QUALITY_BEST}.get(quality, quality)
+    if q not in (_lib.QUALITY_DRAFT, _lib.QUALITY_FAST, _lib.QUALITY_BEST):
+        raise NotImplementedError("Quality mode not implemented.")
+    images = list(images)
+    if not images:
+        return []
+    first = images[0]
+    wb = np.asarray(first.cam_wb.get_reciprocal_multipliers(), dtype=np.float32)
+    mat = first.cam_wb.get_matrix()
+    Mf = final_matrix(mat)
+    hdr = bool(first.get_hdr())
+    mosaics = []
+    for im in images:
+        b = _lib.f32c(im.sensor_scaled)
+        if b.ndim != 2 or b.shape != _lib.f32c(first.sensor_scaled).shape:
+            raise ValueError("debayer_batch: every frame must be a 2-D mosaic of the first frame's size")
+        if b.shape[0] < 2 or b.shape[1] < 2 or b.shape[0] % 2 or b.shape[1] % 2:
+            raise ValueError("demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)" % b.shape)
+        if bool(im.get_hdr()) != hdr or not np.array_equal(np.asarray(im.cam_wb.get_reciprocal_multipliers(), dtype=np.float32), wb) \
+                or not np.array_equal(final_matrix(im.cam_wb.get_matrix()), Mf):
+            raise ValueError("debayer_batch: every frame must share the first frame's white balance, matrix and HDR flag")
+        mosaics.append(b)
+    H, W = mosaics[0].shape
+    outs = [_lib.empty_f32((H, W, 3)) for _ in mosaics]
+    n = len(mosaics)
+    pin = (ctypes.c_void_p * n)(*[m.ctypes.data for m in mosaics])
+    pout = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    ctx = _lib.default_context()
+    with ctx.lock:
+        _lib.check(_lib.lib().pysp_pipeline_batch_f32(ctx.handle, pin, n, H, W, _lib.wb3(wb), _lib.mat9(Mf), q, int(hdr), max(int(postprocess_stages), 0) if q == _lib.QUALITY_BEST else 0,
+                                                      _BATCH_TAILS[to], pout))
+    if to != "image":
+        return outs
+    res = []
+    for im, o in zip(images, outs):
+        d = RawDemosaicData(o, wb, wb_norm=False)
+        d.mat_xyz = im.cam_wb.get_matrix()
+        d.current_ev = im.current_ev
+        res.append(d)
+    return res

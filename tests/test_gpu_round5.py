@@ -331,6 +331,66 @@ def test_frame_whose_result_exceeds_4_GiB(orc):
         assert np.array_equal(srgb[r].cpu().numpy(), orc.lin_srgb_to_srgb(want_lin)), r
 
 
+def test_host_batch_is_one_band_chain_with_the_bits_of_single_calls(orc, wbobj):
+    """pysp_pipeline_batch_f32 / _u16_f32 and debayer_batch: n host frames through one transfer chain (frame k+1 goes up while frame k comes down) == n single
+    calls == the oracle; banded frames (> 4 MP) and small ones, every quality and colour tail, the same mosaic twice in a batch, pageable results (the
+    frame-by-frame fallback), n = 0 and argument errors."""
+    import ctypes
+    from pysp_amd import _lib
+    from pysp_amd.colorize import lin_srgb_to_srgb
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.debayer import debayer_batch
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.synth import rggb_frame
+    wb, M = _wbM(orc)
+    L = _lib.lib()
+    ctx = _lib.Context(0)
+    wbc, Mc = _lib.wb3(wb), _lib.mat9(M)
+
+    def table(arrs):
+        return (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    for (H, W, n) in ((2200, 2048, 3), (96, 128, 5)):
+        frames = [rggb_frame(H, W, 300 + k) for k in range(n)]
+        frames[-1] = frames[0]                                         # the same pages twice in one batch: one page lock, two references
+        for q, stages, tail in ((0, 0, 2), (1, 0, 1), (2, 1, 2), (2, 2, 0)):
+            single = []
+            for f in frames:
+                o = _lib.empty_f32((H, W, 3))
+                _lib.check(L.pysp_pipeline_f32(ctx.handle, _lib.ptr(f), H, W, wbc, Mc, q, 0, stages, tail, _lib.ptr(o)))
+                single.append(o)
+            outs = [_lib.empty_f32((H, W, 3)) for _ in frames]
+            for o in outs: o[:] = -3
+            _lib.check(L.pysp_pipeline_batch_f32(ctx.handle, table(frames), n, H, W, wbc, Mc, q, 0, stages, tail, table(outs)))
+            pag = [np.full((H, W, 3), -3, np.float32) for _ in frames]       # pageable results: frame by frame
+            _lib.check(L.pysp_pipeline_batch_f32(ctx.handle, table(frames), n, H, W, wbc, Mc, q, 0, stages, tail, table(pag)))
+            for k in range(n):
+                assert np.array_equal(outs[k], single[k]) and np.array_equal(pag[k], single[k]), (H, W, q, tail, k)
+        assert np.array_equal(outs[1], orc.demosaic_ahd(frames[1], wb, M, False, 2))                  # (the loop's last configuration: AHD, two stages, tail 0)
+        # uint16 frames
+        raws = [(rggb_frame(H, W, 500 + k) * 15000).astype(np.uint16) for k in range(n)]
+        black, sat = np.array([256, 260, 250, 258], np.float32), np.array([15000, 15100, 14900, 15050], np.float32)
+        bl, sa = (ctypes.c_float * 4)(*black), (ctypes.c_float * 4)(*sat)
+        outs = [_lib.empty_f32((H, W, 3)) for _ in raws]
+        _lib.check(L.pysp_pipeline_batch_u16_f32(ctx.handle, table(raws), n, H, W, bl, sa, wbc, Mc, 2, 0, 1, 2, table(outs)))
+        for k in (0, n - 1):
+            assert np.array_equal(outs[k], orc.pipeline_srgb(orc.bayer_normalize(raws[k], black, sat), wb, M, 2, False, 1, False)), ("u16", H, W, k)
+        # the drop-in level: debayer_batch == the README loop
+        raw_objs = [RawRggbBayerData(f, wbobj, 10.0, 1.0) for f in frames]
+        loop = [lin_srgb_to_srgb(r.demosaic(QualityDemosaic.Best).to_lin_srgb()) for r in raw_objs]
+        got = debayer_batch(raw_objs, QualityDemosaic.Best, 1, to="srgb")
+        assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got, loop))
+        dem = debayer_batch(raw_objs, QualityDemosaic.Fast, to="image")
+        assert all(np.array_equal(np.asarray(d.image), np.asarray(r.demosaic(QualityDemosaic.Fast).image)) for d, r in zip(dem, raw_objs))
+        assert np.array_equal(np.asarray(dem[0].to_lin_srgb()), np.asarray(raw_objs[0].demosaic(QualityDemosaic.Fast).to_lin_srgb()))
+    assert L.pysp_pipeline_batch_f32(ctx.handle, table(frames), 0, H, W, wbc, Mc, 2, 0, 1, 2, table(outs)) == 0
+    assert L.pysp_pipeline_batch_f32(ctx.handle, table(frames), -1, H, W, wbc, Mc, 2, 0, 1, 2, table(outs)) != 0
+    assert L.pysp_pipeline_batch_f32(ctx.handle, table(frames), n, H, W + 1, wbc, Mc, 2, 0, 1, 2, table(outs)) != 0
+    assert L.pysp_pipeline_batch_f32(ctx.handle, table(frames), n, H, W, wbc, Mc, 7, 0, 1, 2, table(outs)) != 0
+    with pytest.raises(ValueError):
+        debayer_batch([RawRggbBayerData(frames[0], wbobj, 10.0, 1.0), RawRggbBayerData(rggb_frame(64, 64, 1), wbobj, 10.0, 1.0)], QualityDemosaic.Best)
+    assert debayer_batch([], QualityDemosaic.Best) == []
+
+
 def test_fusion_keeps_an_exposure_whose_lazy_image_was_read_elsewhere(orc, wbobj):
     """an exposure may hold a DeviceArray whose device copy another holder has released (np.asarray on the shared lazy result moves it to the
     host).  is_valid() counted such an exposure as empty and fuse_exposures_from_debayer dropped it silently; it still resolves through .image and is fused."""

@@ -51,6 +51,23 @@ for it in range(12):
     _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(bay), H, W, wb, M, 2, 0, 1, 0, _lib.ptr(pag_out)))
     ts.append((time.perf_counter() - t0) * 1e3)
 print("one fused call (host buffers, pageable result): min %.2f / median %.2f / max %.2f ms" % (min(ts[1:]), sorted(ts[1:])[len(ts) // 2], max(ts[1:])))
+# a batch of frames through one band chain (pysp_pipeline_batch_f32): ms per frame against the same frames one call each
+nfr = 8
+frames = [rggb_frame(H, W, 2000 + k) for k in range(nfr)]
+outs = [_lib.empty_f32((H, W, 3)) for _ in range(nfr)]
+tab = lambda arrs: (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+for q, name in ((2, "AHD + sRGB"), (1, "EAG + sRGB")):
+    tb, tsn = [], []
+    for it in range(6):
+        t0 = time.perf_counter()
+        _lib.check(L.pysp_pipeline_batch_f32(ctx.handle, tab(frames), nfr, H, W, wb, M, q, 0, 1, 2, tab(outs)))
+        tb.append((time.perf_counter() - t0) * 1e3 / nfr)
+        t0 = time.perf_counter()
+        for f, o in zip(frames, outs):
+            _lib.check(L.pysp_pipeline_srgb_f32(ctx.handle, _lib.ptr(f), H, W, wb, M, q, 0, 1, 0, _lib.ptr(o)))
+        tsn.append((time.perf_counter() - t0) * 1e3 / nfr)
+    print("batch of %d host frames, %s: one chain min %.2f / median %.2f ms per frame = %.2f GMP/s; one call per frame min %.2f / median %.2f ms" %
+          (nfr, name, min(tb[1:]), sorted(tb[1:])[len(tb) // 2], H * W / 1e6 / sorted(tb[1:])[len(tb) // 2], min(tsn[1:]), sorted(tsn[1:])[len(tsn) // 2]))
 # raw copy rates
 d = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
 pin = torch.empty(H * W * 3, dtype=torch.float32).pin_memory()
