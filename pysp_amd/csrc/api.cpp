@@ -106,6 +106,16 @@ struct HostPins {
 HostPins& host_pins() { static HostPins* b = new HostPins; return *b; }      // (never destroyed: a call may still be running on another thread at exit)
 
 // even, >= 2 and <= 2^20 per side: the kernels form tile-local byte offsets with 24-bit multiplies (row * W * 12 bytes), and no sensor is near that
+// Band geometry of the host pipelines: output rows per band (even; PYSP_BAND_ROWS) and the frame size from which a frame is cut into bands at all
+// (PYSP_BAND_MIN_PX, default 2^22 pixels).  Read on every call, not once: the seam tests vary both inside one process.
+int band_rows_env() { const char* e = getenv("PYSP_BAND_ROWS"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 1) & ~1 : 0; }
+int band_halo(int stages) {       // PYSP_BAND_HALO_DELTA (tests only: a negative control that starves the halo and must make the seams show)
+    const char* e = getenv("PYSP_BAND_HALO_DELTA");
+    int h = 8 + 4 * stages + (e ? atoi(e) : 0);
+    h &= ~1;                      // (even: a band starts on a CFA row pair)
+    return h < 0 ? 0 : h;
+}
+size_t band_min_px_env() { const char* e = getenv("PYSP_BAND_MIN_PX"); long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : ((size_t)1 << 22); }
 bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && H <= (1 << 20) && W <= (1 << 20); }
 
 }  // namespace
@@ -809,11 +819,11 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     if (!even_dims(H, W)) return fail(PYSP_EBADARG, "demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)", H, W);
     if (quality < PYSP_QUALITY_DRAFT || quality > PYSP_QUALITY_BEST) return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
     const int st = stages < 0 ? 0 : stages;
-    const int halo = 8 + 4 * st;
-    static const int band_env = [] { const char* e = getenv("PYSP_BAND_ROWS"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 1) & ~1 : 0; }();
+    const int halo = band_halo(st);
+    const int band_env = band_rows_env();
     int band = band_env ? band_env : 256;                        // output rows per band (even; measured at 24 MP: 128 rows 6.13 ms, 256 5.94, 512 6.00, 1024 6.20 per fused call); PYSP_BAND_ROWS overrides
     const size_t px = (size_t)H * W;
-    int nb = px < ((size_t)1 << 22) ? 1 : (H + band - 1) / band;  // small frames: one piece
+    int nb = px < band_min_px_env() ? 1 : (H + band - 1) / band;  // small frames: one piece
     if (nb < 2) { nb = 1; band = H; }
     const int max_rows = (band + 2 * halo) < H ? (band + 2 * halo) : H;
     T* d_in[2]; float* d_out[2];
@@ -1102,10 +1112,10 @@ static int run_pipeline_host_batch_t(pysp_ctx* ctx, const T* const* bayers, cons
         return PYSP_OK;
     }
     const int st = stages < 0 ? 0 : stages;
-    const int halo = 8 + 4 * st;
-    static const int band_env = [] { const char* e = getenv("PYSP_BAND_ROWS"); int v = e ? atoi(e) : 0; return v > 0 ? (v + 1) & ~1 : 0; }();
+    const int halo = band_halo(st);
+    const int band_env = band_rows_env();
     int band = band_env ? band_env : 256;
-    int nb = px < ((size_t)1 << 22) ? 1 : (H + band - 1) / band;      // small frames: one piece each, still chained frame to frame
+    int nb = px < band_min_px_env() ? 1 : (H + band - 1) / band;      // small frames: one piece each, still chained frame to frame
     if (nb < 2) { nb = 1; band = H; }
     const int max_rows = (band + 2 * halo) < H ? (band + 2 * halo) : H;
     T* d_in[2]; float* d_out[2];

@@ -391,6 +391,83 @@ def test_host_batch_is_one_band_chain_with_the_bits_of_single_calls(orc, wbobj):
     assert debayer_batch([], QualityDemosaic.Best) == []
 
 
+def test_band_seams_of_the_host_pipelines_on_random_geometry(orc):
+    """The host entry points cut a frame into row bands with 8 + 4 * stages halo rows from the input on either side (api.cpp, as multi_gpu.band_ranges): a
+    band must reproduce the rows of the whole-frame launch whatever the band height, the frame height (last band short, bands shorter than the halo, a
+    single band) and the content.  500 random cases with PYSP_BAND_MIN_PX=1 and PYSP_BAND_ROWS random in 2..80: every quality, 0..3 median stages, every
+    tail, HDR metric, page-locked results (event chain), pageable results (helper thread) and the batch chain, against the device-resident whole-frame call
+    of the same library (bit for bit) and, every tenth case, against the oracle."""
+    import ctypes
+    import os
+    from pysp_amd import _lib
+    wb, M = _wbM(orc)
+    L = _lib.lib()
+    ctx = _lib.Context(0)
+    wbc, Mc = _lib.wb3(wb), _lib.mat9(M)
+    rng = np.random.default_rng(20261007)
+    old = {k: os.environ.get(k) for k in ("PYSP_BAND_MIN_PX", "PYSP_BAND_ROWS")}
+    try:
+        os.environ["PYSP_BAND_MIN_PX"] = "1"
+        for case in range(500):
+            H, W = 2 * int(rng.integers(1, 150)), 2 * int(rng.integers(1, 100))
+            os.environ["PYSP_BAND_ROWS"] = str(2 * int(rng.integers(1, 41)))
+            kind = int(rng.integers(0, 3))
+            bay = (rng.random((H, W)) if kind == 0 else np.round(rng.random((H, W)) * 4) / 4 if kind == 1 else rng.random((H, W)) ** 3).astype(np.float32)
+            q = int(rng.integers(0, 3))
+            stages = int(rng.integers(0, 4)) if q == 2 else 0
+            hdr = int(rng.integers(0, 2)) if q == 2 else 0
+            tail = int(rng.integers(0, 4))
+            d_in = _lib.lib().pysp_dev_alloc(ctx.handle, ctypes.c_size_t(bay.nbytes))
+            d_out = _lib.lib().pysp_dev_alloc(ctx.handle, ctypes.c_size_t(bay.nbytes * 3))
+            assert d_in and d_out
+            whole = np.empty((H, W, 3), np.float32)
+            _lib.check(L.pysp_dev_upload(ctx.handle, ctypes.c_void_p(d_in), _lib.ptr(bay), ctypes.c_size_t(bay.nbytes)))
+            _lib.check(L.pysp_pipeline_dev(ctx.handle, ctypes.c_void_p(d_in), H, W, wbc, Mc, q, hdr, stages, tail, ctypes.c_void_p(d_out)))
+            _lib.check(L.pysp_dev_download(ctx.handle, _lib.ptr(whole), ctypes.c_void_p(d_out), ctypes.c_size_t(whole.nbytes)))
+            L.pysp_dev_free(ctx.handle, ctypes.c_void_p(d_in)); L.pysp_dev_free(ctx.handle, ctypes.c_void_p(d_out))
+            how = case % 3
+            if how == 0:                                    # page-locked result: the event chain
+                hp = L.pysp_host_alloc(ctypes.c_size_t(whole.nbytes))
+                assert hp
+                got = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_float)), shape=(H, W, 3))
+                got[:] = -5
+                _lib.check(L.pysp_pipeline_f32(ctx.handle, _lib.ptr(bay), H, W, wbc, Mc, q, hdr, stages, tail, ctypes.c_void_p(hp)))
+                same = np.array_equal(got, whole, equal_nan=True)
+                L.pysp_host_free(ctypes.c_void_p(hp))
+            elif how == 1:                                  # pageable result: the helper thread
+                got = np.full((H, W, 3), -5, np.float32)
+                _lib.check(L.pysp_pipeline_f32(ctx.handle, _lib.ptr(bay), H, W, wbc, Mc, q, hdr, stages, tail, _lib.ptr(got)))
+                same = np.array_equal(got, whole, equal_nan=True)
+            else:                                           # the batch chain, the frame twice
+                hp = [L.pysp_host_alloc(ctypes.c_size_t(whole.nbytes)) for _ in range(2)]
+                assert all(hp)
+                gots = [np.ctypeslib.as_array(ctypes.cast(h, ctypes.POINTER(ctypes.c_float)), shape=(H, W, 3)) for h in hp]
+                for g_ in gots: g_[:] = -5
+                _lib.check(L.pysp_pipeline_batch_f32(ctx.handle, (ctypes.c_void_p * 2)(bay.ctypes.data, bay.ctypes.data), 2, H, W, wbc, Mc, q, hdr, stages, tail, (ctypes.c_void_p * 2)(*hp)))
+                same = all(np.array_equal(g_, whole, equal_nan=True) for g_ in gots)
+                for h in hp: L.pysp_host_free(ctypes.c_void_p(h))
+            assert same, (case, H, W, os.environ["PYSP_BAND_ROWS"], q, stages, hdr, tail, how)
+            if case % 10 == 0 and tail in (0, 2) and not hdr:
+                want = orc.pipeline_srgb(bay, wb, M, q, False, stages, False) if tail == 2 else (orc.demosaic_ahd(bay, wb, M, False, stages) if q == 2 else orc.demosaic_eag(bay, wb) if q == 1 else orc.demosaic_draft(bay, wb))
+                assert np.array_equal(whole, want), (case, "oracle")
+        # negative control: with the halo starved (PYSP_BAND_HALO_DELTA, a test-only switch) the same comparison must FAIL on noise -- the bands are really cut
+        os.environ["PYSP_BAND_HALO_DELTA"] = "-6"
+        os.environ["PYSP_BAND_ROWS"] = "16"
+        H, W = 96, 64
+        bay = rng.random((H, W)).astype(np.float32)
+        whole, got = orc.demosaic_ahd(bay, wb, M, False, 1), np.empty((H, W, 3), np.float32)
+        _lib.check(L.pysp_pipeline_f32(ctx.handle, _lib.ptr(bay), H, W, wbc, Mc, 2, 0, 1, 0, _lib.ptr(got)))
+        assert not np.array_equal(got, whole)
+        os.environ.pop("PYSP_BAND_HALO_DELTA")
+        _lib.check(L.pysp_pipeline_f32(ctx.handle, _lib.ptr(bay), H, W, wbc, Mc, 2, 0, 1, 0, _lib.ptr(got)))
+        assert np.array_equal(got, whole)
+    finally:
+        os.environ.pop("PYSP_BAND_HALO_DELTA", None)
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
 def test_fusion_keeps_an_exposure_whose_lazy_image_was_read_elsewhere(orc, wbobj):
     """an exposure may hold a DeviceArray whose device copy another holder has released (np.asarray on the shared lazy result moves it to the
     host).  is_valid() counted such an exposure as empty and fuse_exposures_from_debayer dropped it silently; it still resolves through .image and is fused."""
