@@ -109,7 +109,7 @@ int pysp_ctx_get_lab_lut(pysp_ctx *ctx, int16_t *out);
 int pysp_ctx_sync(pysp_ctx *ctx);
 /* Duration in ms of the most recent *_dev or host call's kernels on this context (HIP events on
  * the context's stream; waits for completion).  A host call on a frame of more than 4 MP runs in overlapped
- * 256-row bands: the two timing queries then describe the LAST band only (about 1/16 of a 24 MP frame);
+ * row bands: the two timing queries then describe the LAST band only (about a third of a 24 MP frame);
  * time whole frames with the *_dev entry points.  A host fusion of more exposures than one pass takes
  * (pysp_fuse_raw_f32 / pysp_fuse_rgb_f32, K > 16 / 12) is timed from its first pass's kernel to its last pass's:
  * the later passes' uploads lie in between, so that figure is not kernel-only (pysp_ctx_kernel_times lists the passes). */

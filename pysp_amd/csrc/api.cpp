@@ -115,6 +115,29 @@ int band_halo(int stages) {       // PYSP_BAND_HALO_DELTA (tests only: a negativ
     h &= ~1;                      // (even: a band starts on a CFA row pair)
     return h < 0 ? 0 : h;
 }
+// The bands of a frame: row starts ys[0] = 0 < ys[1] < ... < ys[nb] = H (all even).  PYSP_BAND_ROWS set: uniform bands of that height (the seam tests; the
+// measurements of round 2: 128 rows 6.13 ms, 256 5.94, 512 6.00, 1024 6.20 per fused 24 MP call).  Default (round 5): a RAMP -- a first band of ~0.75 MP so that the
+// first download starts after 0.1 ms, then bands twice as large each (band g's upload + kernels still fit inside band g-1's download) up to ~6 MP: six bands
+// instead of sixteen at 24 MP.  Every band boundary costs the download engine ~10 us (the cross-stream hand-over) and every band re-uploads 2 x halo rows.
+extern "C++" std::vector<int> band_schedule(int H, int W, size_t min_px) {
+    std::vector<int> ys{0};
+    const size_t px = (size_t)H * W;
+    if (px < min_px) { ys.push_back(H); return ys; }
+    const int uni = band_rows_env();
+    if (uni) { for (int y = uni; y < H; y += uni) ys.push_back(y); ys.push_back(H); return ys; }
+    auto rows_of = [&](size_t bpx) { long r = (long)((bpx + (size_t)W - 1) / (size_t)W); r = (r + 1) & ~1L; return (int)(r < 64 ? 64 : r); };
+    auto env_px = [](const char* name, size_t dflt) { const char* e = getenv(name); long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : dflt; };
+    int cur = rows_of(env_px("PYSP_BAND_FIRST_PX", 512 * 1024));                        // (the two knobs of the ramp, for tools/dropin_probe.py)
+    const int cap = rows_of(env_px("PYSP_BAND_CAP_PX", 12 * 1024 * 1024));
+    int y = 0;
+    while (y < H) {
+        int b = cur < H - y ? cur : H - y;
+        if (H - y - b < cur / 2) b = H - y;               // a short leftover joins the band before it
+        y += b; ys.push_back(y);
+        cur = cur * 2 < cap ? cur * 2 : cap;
+    }
+    return ys;
+}
 size_t band_min_px_env() { const char* e = getenv("PYSP_BAND_MIN_PX"); long long v = e ? atoll(e) : 0; return v > 0 ? (size_t)v : ((size_t)1 << 22); }
 bool even_dims(int H, int W) { return H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && H <= (1 << 20) && W <= (1 << 20); }
 
@@ -706,6 +729,89 @@ int pysp_flat_field_f32(pysp_ctx* ctx, const float* bayer, const float* flat, in
     return pysp_ctx_sync(ctx);
 }
 
+// The asynchronous band chain of the host pipelines (round 5): n frames of one geometry, every result page-locked and every mosaic page-locked for the
+// duration (the CALLER holds the locks: run_pipeline_host_t for one frame, run_pipeline_host_batch_t for a batch).  Per band: upload on its own stream ->
+// kernels -> download on its own stream, chained with events; two buffer pairs alternate over the whole batch.  One host thread, and it stays at most
+// `depth` bands ahead of the device (below).
+extern "C++" template <typename T>
+static int run_chain_t(pysp_ctx* ctx, const T* const* bayers, const float* black, const float* sat, int n, int H, int W, const float wb[3],
+                       const double M[9], int quality, int hdr, int stages, int tail, float* const* outs) {
+    const int st = stages < 0 ? 0 : stages;
+    const int halo = band_halo(st);
+    const std::vector<int> ys = band_schedule(H, W, band_min_px_env());      // small frames: one piece each, still chained frame to frame
+    const int nb = (int)ys.size() - 1;
+    int max_rows = 0;
+    for (int b = 0; b < nb; b++) {
+        const int r0 = ys[b] - halo > 0 ? ys[b] - halo : 0, r1 = ys[b + 1] + halo < H ? ys[b + 1] + halo : H;
+        if (r1 - r0 > max_rows) max_rows = r1 - r0;
+    }
+    T* d_in[2]; float* d_out[2];
+    for (int i = 0; i < 2; i++) {
+        RESERVE(ctx, i == 0 ? S_IN : S_IN2, (size_t)max_rows * W * sizeof(T), d_in[i]);
+        RESERVE(ctx, i == 0 ? S_OUT : S_OUT2, (size_t)max_rows * W * 12, d_out[i]);
+    }
+    if (quality == PYSP_QUALITY_BEST) {
+        void* t;
+        if (st >= 1) RESERVE(ctx, S_TMP0, (size_t)max_rows * W * 12, t);
+        if (st >= 2) RESERVE(ctx, S_TMP1, (size_t)max_rows * W * 12, t);
+    }
+    if (!ctx->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
+    }
+    auto mosaic = [&](const T* d) { return sizeof(T) == 2 ? mosaic_u16(reinterpret_cast<const uint16_t*>(d), black, sat) : mosaic_f32(reinterpret_cast<const float*>(d)); };
+    // The host runs ahead of the device by `depth` bands at most (default 2: it enqueues band g once band g-2 has landed; the two buffer pairs allow two bands
+    // in flight anyway, and band g's upload + kernels, 0.15 ms, fit inside band g-1's download, 0.32 ms).  Enqueueing further ahead makes this runtime SLOWER,
+    // not faster -- measured at 24 MP, 8 frames, ms per frame (tools/batch_probe.py): depth 2 / 3: 5.80, 4: 10.1, 8: 27.2, 16: 12.6, no limit: 16-24 -- while the
+    // single call (16 bands, no limit, one drain per frame) takes 5.93.  PYSP_BATCH_DEPTH overrides.
+    static const int depth_env = [] { const char* e = getenv("PYSP_BATCH_DEPTH"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > pysp_ctx::RING ? pysp_ctx::RING : v; }();
+    const int depth = depth_env ? depth_env : 2;
+    for (int i = 0; i < pysp_ctx::RING; i++) if (!ctx->ev_ring[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ring[i], hipEventDisableTiming));
+    static const bool btrace = [] { const char* e = getenv("PYSP_BAND_TRACE"); return e && e[0] == '1'; }();
+    static const bool d2h_kernel = [] { const char* e = getenv("PYSP_D2H_KERNEL"); return e && e[0] == '1'; }();
+    const auto bt0 = std::chrono::steady_clock::now();
+    int rc = PYSP_OK;
+    long g = 0;                                                        // band number over the whole batch: the two buffer pairs alternate across frame borders
+    for (int f = 0; f < n && rc == PYSP_OK; f++) {
+        const T* const bayer = bayers[f];
+        float* const out = outs[f];
+        for (int b = 0; b < nb && rc == PYSP_OK; b++, g++) {
+            const int i = (int)(g & 1), y0 = ys[b], y1 = ys[b + 1];
+            const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
+            if (g >= depth) HIP_TRY(hipEventSynchronize(ctx->ev_ring[(g - depth) % pysp_ctx::RING]));      // band g-depth has landed
+            if (g >= 2) HIP_TRY(hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0));      // d_in[i]: the kernels of band g-2 have read it
+            HIP_TRY(hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->up_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_up[i], ctx->up_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[i], 0));
+            if (g >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_free[i], 0));          // d_out[i]: band g-2 has left it
+            rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
+            if (rc != PYSP_OK) break;
+            HIP_TRY(hipEventRecord(ctx->ev_done[i], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0));
+            float* const dst = out + (size_t)y0 * W * 3;
+            const float* const src = d_out[i] + (size_t)(y0 - r0) * W * 3;
+            const size_t nbytes = (size_t)(y1 - y0) * W * 12;
+            if (d2h_kernel && launch_copy16(ctx->copy_stream, dst, src, nbytes) == 0) { }      // PYSP_D2H_KERNEL=1: a copy kernel instead of a DMA engine (experiment)
+            else HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_free[i], ctx->copy_stream));
+            HIP_TRY(hipEventRecord(ctx->ev_ring[g % pysp_ctx::RING], ctx->copy_stream));
+        }
+        if (btrace) fprintf(stderr, "[pysp batch trace] frame %d enqueued at %.2f ms\n", f, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bt0).count());
+    }
+    hipError_t e = hipStreamSynchronize(ctx->copy_stream);             // (on an error above the enqueued work still drains here: the buffers belong to the context)
+    if (btrace) {
+        fprintf(stderr, "[pysp band trace, chain] %d frame(s) x %d bands (rows", n, nb);
+        for (int b = 0; b < nb && b < 12; b++) fprintf(stderr, " %d", ys[b + 1] - ys[b]);
+        fprintf(stderr, "%s), run-ahead %d, all copied %.2f ms\n", nb > 12 ? " ..." : "", depth, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bt0).count());
+    }
+    if (rc != PYSP_OK) return rc;
+    if (e != hipSuccess) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(e));
+    return pysp_ctx_sync(ctx);
+}
+
 // ---- demosaic / fused pipeline ----------------------------------------------------------------------
 static int run_pipeline_src(pysp_ctx* ctx, const MosaicSrc& src, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
                             int stages, int tail, float* d_out) {
@@ -820,12 +926,14 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     if (quality < PYSP_QUALITY_DRAFT || quality > PYSP_QUALITY_BEST) return fail(PYSP_ENOTIMPL, "Quality mode not implemented: %d", quality);
     const int st = stages < 0 ? 0 : stages;
     const int halo = band_halo(st);
-    const int band_env = band_rows_env();
-    int band = band_env ? band_env : 256;                        // output rows per band (even; measured at 24 MP: 128 rows 6.13 ms, 256 5.94, 512 6.00, 1024 6.20 per fused call); PYSP_BAND_ROWS overrides
     const size_t px = (size_t)H * W;
-    int nb = px < band_min_px_env() ? 1 : (H + band - 1) / band;  // small frames: one piece
-    if (nb < 2) { nb = 1; band = H; }
-    const int max_rows = (band + 2 * halo) < H ? (band + 2 * halo) : H;
+    const std::vector<int> ys = band_schedule(H, W, band_min_px_env());      // small frames: one piece
+    const int nb = (int)ys.size() - 1;
+    int max_rows = 0;
+    for (int b = 0; b < nb; b++) {
+        const int r0 = ys[b] - halo > 0 ? ys[b] - halo : 0, r1 = ys[b + 1] + halo < H ? ys[b + 1] + halo : H;
+        if (r1 - r0 > max_rows) max_rows = r1 - r0;
+    }
     T* d_in[2]; float* d_out[2];
     for (int i = 0; i < (nb > 1 ? 2 : 1); i++) {
         RESERVE(ctx, i == 0 ? S_IN : S_IN2, (size_t)max_rows * W * sizeof(T), d_in[i]);
@@ -889,49 +997,15 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     const int in_pin = host_pins().acquire(bayer, px * sizeof(T), want_register, &reg_ms);      // 2: ours for the call, 1: the caller's own, 0: pageable
     if (in_pin == 2) { reg.p = bayer; reg.n = px * sizeof(T); }
     if (trace && want_register) fprintf(stderr, "[pysp band trace] mosaic %s (hipHostRegister %.2f ms)\n", in_pin == 2 ? "page-locked for the call" : in_pin == 1 ? "page-locked by the caller" : "pageable", reg_ms);
-    static const bool d2h_kernel = [] { const char* e = getenv("PYSP_D2H_KERNEL"); return e && e[0] == '1'; }();
     static const int pipe_events = [] { const char* e = getenv("PYSP_HOST_PIPE"); return e && !strcmp(e, "events") ? 1 : 0; }();
     // (a pageable mosaic keeps the helper-thread form: next to queued asynchronous downloads the runtime's blocking pageable upload takes 0.53 ms per band
     // instead of 0.12 -- 8.7 ms per frame, profiles/r5_dropin_probe.log -- unless the mosaic was page-locked for the call, PYSP_H2D_REGISTER=1)
     if (!pipe_env && out_pinned && (pipe_events || in_pin)) {
-        std::vector<double> tr;
-        int rc = PYSP_OK;
-        for (int b = 0; b < nb && rc == PYSP_OK; b++) {
-            const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
-            const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
-            // The upload has a stream of its own.  A copy from PAGEABLE memory is not asynchronous: the runtime first waits, on the host, for everything its
-            // stream holds -- on the kernels' stream that included the wait for band b-2's download (measured: 0.53 ms per band instead of 0.12, 8.6 ms per
-            // 24 MP frame instead of 5.9, profiles/r5_dropin_probe.log).  Here it only waits for the kernels of band b-2, which read d_in[i] and finished long ago.
-            if (b >= 2) HIP_TRY(hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0));
-            if (trace) tr.push_back(ms_since(clk::now()));
-            HIP_TRY(hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->up_stream));
-            HIP_TRY(hipEventRecord(ctx->ev_up[i], ctx->up_stream));
-            if (trace) tr.push_back(ms_since(clk::now()));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[i], 0));
-            if (b >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_free[i], 0));      // d_out[i] may be overwritten once band b-2 has left it (a device-side wait)
-            rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
-            if (rc != PYSP_OK) break;
-            HIP_TRY(hipEventRecord(ctx->ev_done[i], ctx->stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0));
-            float* const dst = out + (size_t)y0 * W * 3;
-            const float* const src = d_out[i] + (size_t)(y0 - r0) * W * 3;
-            const size_t nbytes = (size_t)(y1 - y0) * W * 12;
-            if (d2h_kernel && launch_copy16(ctx->copy_stream, dst, src, nbytes) == 0) { }
-            else HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-            HIP_TRY(hipEventRecord(ctx->ev_free[i], ctx->copy_stream));
-            if (trace) tr.push_back(ms_since(clk::now()));
-        }
-        // (on an error above the enqueued work still drains below: the buffers belong to the context)
-        hipError_t e = hipStreamSynchronize(ctx->copy_stream);
-        if (trace) {
-            tr.push_back(ms_since(clk::now()));
-            fprintf(stderr, "[pysp band trace, events] %d bands:", nb);
-            for (size_t k = 0; k + 2 < tr.size(); k += 3) fprintf(stderr, " %.2f/%.2f/%.2f", tr[k], tr[k + 1], tr[k + 2]);
-            fprintf(stderr, " | all copied %.2f ms\n", tr.back());
-        }
-        if (rc != PYSP_OK) return rc;
-        if (e != hipSuccess) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(e));
-        return pysp_ctx_sync(ctx);
+        // the asynchronous chain (shared with the batch entry points); `reg` keeps the mosaic page-locked until every stream has drained
+        // (PYSP_HOST_PIPE=events with a pageable mosaic, an experiment switch: the upload is then the runtime's blocking one -- 0.53 ms per band next to queued downloads)
+        const T* const one_in[1] = {bayer};
+        float* const one_out[1] = {out};
+        return run_chain_t<T>(ctx, one_in, black, sat, 1, H, W, wb, M, quality, hdr, stages, tail, one_out);
     }
     // produced[b]: band b's kernels are enqueued and ev_done[b & 1] recorded; consumed: bands whose download has finished
     std::atomic<int> produced{0}, consumed{0}, worker_rc{PYSP_OK}, worker_err{(int)hipSuccess};    // worker_err: the hipError_t the WORKER saw (hipGetLastError is per thread)
@@ -941,7 +1015,7 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
         { hipError_t e0 = hipSetDevice(device); if (e0 != hipSuccess) { worker_err = (int)e0; worker_rc = PYSP_EHIP; consumed = nb; return; } }
         for (int b = 0; b < nb; b++) {
             while (produced.load(std::memory_order_acquire) <= b) { if (abort.load()) { consumed = nb; return; } std::this_thread::yield(); }
-            const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H, r0 = y0 - halo > 0 ? y0 - halo : 0;
+            const int i = b & 1, y0 = ys[b], y1 = ys[b + 1], r0 = y0 - halo > 0 ? y0 - halo : 0;
             hipError_t e = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0);
             if (d2h_sync) {
                 e = hipEventSynchronize(ctx->ev_done[i]);
@@ -957,7 +1031,7 @@ static int run_pipeline_host_t(pysp_ctx* ctx, const T* bayer, const float* black
     int rc = PYSP_OK;
     std::vector<double> ttr;
     for (int b = 0; b < nb && rc == PYSP_OK; b++) {
-        const int i = b & 1, y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
+        const int i = b & 1, y0 = ys[b], y1 = ys[b + 1];
         const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
         // upload on its own stream (see the event-chained form above): it waits for the kernels of band b-2 only, not for that band's download
         hipError_t e = b >= 2 ? hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0) : hipSuccess;
@@ -1111,68 +1185,7 @@ static int run_pipeline_host_batch_t(pysp_ctx* ctx, const T* const* bayers, cons
         for (int f = 0; f < n; f++) TRY(run_pipeline_host_t<T>(ctx, bayers[f], black, sat, H, W, wb, M, quality, hdr, stages, tail, outs[f]));
         return PYSP_OK;
     }
-    const int st = stages < 0 ? 0 : stages;
-    const int halo = band_halo(st);
-    const int band_env = band_rows_env();
-    int band = band_env ? band_env : 256;
-    int nb = px < band_min_px_env() ? 1 : (H + band - 1) / band;      // small frames: one piece each, still chained frame to frame
-    if (nb < 2) { nb = 1; band = H; }
-    const int max_rows = (band + 2 * halo) < H ? (band + 2 * halo) : H;
-    T* d_in[2]; float* d_out[2];
-    for (int i = 0; i < 2; i++) {
-        RESERVE(ctx, i == 0 ? S_IN : S_IN2, (size_t)max_rows * W * sizeof(T), d_in[i]);
-        RESERVE(ctx, i == 0 ? S_OUT : S_OUT2, (size_t)max_rows * W * 12, d_out[i]);
-    }
-    if (quality == PYSP_QUALITY_BEST) {
-        void* t;
-        if (st >= 1) RESERVE(ctx, S_TMP0, (size_t)max_rows * W * 12, t);
-        if (st >= 2) RESERVE(ctx, S_TMP1, (size_t)max_rows * W * 12, t);
-    }
-    if (!ctx->copy_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
-    }
-    auto mosaic = [&](const T* d) { return sizeof(T) == 2 ? mosaic_u16(reinterpret_cast<const uint16_t*>(d), black, sat) : mosaic_f32(reinterpret_cast<const float*>(d)); };
-    // The host runs ahead of the device by `depth` bands at most (default 2: it enqueues band g once band g-2 has landed; the two buffer pairs allow two bands
-    // in flight anyway, and band g's upload + kernels, 0.15 ms, fit inside band g-1's download, 0.32 ms).  Enqueueing further ahead makes this runtime SLOWER,
-    // not faster -- measured at 24 MP, 8 frames, ms per frame (tools/batch_probe.py): depth 2 / 3: 5.80, 4: 10.1, 8: 27.2, 16: 12.6, no limit: 16-24 -- while the
-    // single call (16 bands, no limit, one drain per frame) takes 5.93.  PYSP_BATCH_DEPTH overrides.
-    static const int depth_env = [] { const char* e = getenv("PYSP_BATCH_DEPTH"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > pysp_ctx::RING ? pysp_ctx::RING : v; }();
-    const int depth = depth_env ? depth_env : 2;
-    for (int i = 0; i < pysp_ctx::RING; i++) if (!ctx->ev_ring[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ring[i], hipEventDisableTiming));
-    static const bool btrace = [] { const char* e = getenv("PYSP_BAND_TRACE"); return e && e[0] == '1'; }();
-    const auto bt0 = std::chrono::steady_clock::now();
-    int rc = PYSP_OK;
-    long g = 0;                                                        // band number over the whole batch: the two buffer pairs alternate across frame borders
-    for (int f = 0; f < n && rc == PYSP_OK; f++) {
-        const T* const bayer = bayers[f];
-        float* const out = outs[f];
-        for (int b = 0; b < nb && rc == PYSP_OK; b++, g++) {
-            const int i = (int)(g & 1), y0 = b * band, y1 = y0 + band < H ? y0 + band : H;
-            const int r0 = y0 - halo > 0 ? y0 - halo : 0, r1 = y1 + halo < H ? y1 + halo : H;
-            if (g >= depth) HIP_TRY(hipEventSynchronize(ctx->ev_ring[(g - depth) % pysp_ctx::RING]));      // band g-depth has landed
-            if (g >= 2) HIP_TRY(hipStreamWaitEvent(ctx->up_stream, ctx->ev_done[i], 0));      // d_in[i]: the kernels of band g-2 have read it
-            HIP_TRY(hipMemcpyAsync(d_in[i], bayer + (size_t)r0 * W, (size_t)(r1 - r0) * W * sizeof(T), hipMemcpyHostToDevice, ctx->up_stream));
-            HIP_TRY(hipEventRecord(ctx->ev_up[i], ctx->up_stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_up[i], 0));
-            if (g >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_free[i], 0));          // d_out[i]: band g-2 has left it
-            rc = run_pipeline_src(ctx, mosaic(d_in[i]), r1 - r0, W, wb, M, quality, hdr, stages, tail, d_out[i]);
-            if (rc != PYSP_OK) break;
-            HIP_TRY(hipEventRecord(ctx->ev_done[i], ctx->stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_done[i], 0));
-            HIP_TRY(hipMemcpyAsync(out + (size_t)y0 * W * 3, d_out[i] + (size_t)(y0 - r0) * W * 3, (size_t)(y1 - y0) * W * 12, hipMemcpyDeviceToHost, ctx->copy_stream));
-            HIP_TRY(hipEventRecord(ctx->ev_free[i], ctx->copy_stream));
-            HIP_TRY(hipEventRecord(ctx->ev_ring[g % pysp_ctx::RING], ctx->copy_stream));
-        }
-        if (btrace) fprintf(stderr, "[pysp batch trace] frame %d enqueued at %.2f ms\n", f, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - bt0).count());
-    }
-    hipError_t e = hipStreamSynchronize(ctx->copy_stream);             // (on an error above the enqueued work still drains here: the buffers belong to the context)
-    if (rc != PYSP_OK) return rc;
-    if (e != hipSuccess) return fail(PYSP_EHIP, "device-to-host copy of a band failed: %s", hipGetErrorString(e));
-    return pysp_ctx_sync(ctx);
+    return run_chain_t<T>(ctx, bayers, black, sat, n, H, W, wb, M, quality, hdr, stages, tail, outs);
 }
 int pysp_pipeline_batch_f32(pysp_ctx* ctx, const float* const* bayers, int n_frames, int H, int W, const float wb[3], const double M[9], int quality, int hdr,
                             int stages, int tail, float* const* outs) {

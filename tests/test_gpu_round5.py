@@ -405,12 +405,18 @@ def test_band_seams_of_the_host_pipelines_on_random_geometry(orc):
     ctx = _lib.Context(0)
     wbc, Mc = _lib.wb3(wb), _lib.mat9(M)
     rng = np.random.default_rng(20261007)
-    old = {k: os.environ.get(k) for k in ("PYSP_BAND_MIN_PX", "PYSP_BAND_ROWS")}
+    old = {k: os.environ.get(k) for k in ("PYSP_BAND_MIN_PX", "PYSP_BAND_ROWS", "PYSP_BAND_FIRST_PX", "PYSP_BAND_CAP_PX")}
     try:
         os.environ["PYSP_BAND_MIN_PX"] = "1"
         for case in range(500):
             H, W = 2 * int(rng.integers(1, 150)), 2 * int(rng.integers(1, 100))
-            os.environ["PYSP_BAND_ROWS"] = str(2 * int(rng.integers(1, 41)))
+            if case % 5 == 4:                                # the default schedule: a ramp (first band, doubling, cap, short leftover joined), here with small knobs
+                os.environ.pop("PYSP_BAND_ROWS", None)
+                H = 2 * int(rng.integers(30, 600))
+                os.environ["PYSP_BAND_FIRST_PX"] = str(int(rng.integers(1, 40)) * W * 4)
+                os.environ["PYSP_BAND_CAP_PX"] = str(int(rng.integers(20, 200)) * W * 4)
+            else:
+                os.environ["PYSP_BAND_ROWS"] = str(2 * int(rng.integers(1, 41)))
             kind = int(rng.integers(0, 3))
             bay = (rng.random((H, W)) if kind == 0 else np.round(rng.random((H, W)) * 4) / 4 if kind == 1 else rng.random((H, W)) ** 3).astype(np.float32)
             q = int(rng.integers(0, 3))
@@ -446,12 +452,13 @@ def test_band_seams_of_the_host_pipelines_on_random_geometry(orc):
                 _lib.check(L.pysp_pipeline_batch_f32(ctx.handle, (ctypes.c_void_p * 2)(bay.ctypes.data, bay.ctypes.data), 2, H, W, wbc, Mc, q, hdr, stages, tail, (ctypes.c_void_p * 2)(*hp)))
                 same = all(np.array_equal(g_, whole, equal_nan=True) for g_ in gots)
                 for h in hp: L.pysp_host_free(ctypes.c_void_p(h))
-            assert same, (case, H, W, os.environ["PYSP_BAND_ROWS"], q, stages, hdr, tail, how)
+            assert same, (case, H, W, os.environ.get("PYSP_BAND_ROWS"), os.environ.get("PYSP_BAND_FIRST_PX"), os.environ.get("PYSP_BAND_CAP_PX"), q, stages, hdr, tail, how)
             if case % 10 == 0 and tail in (0, 2) and not hdr:
                 want = orc.pipeline_srgb(bay, wb, M, q, False, stages, False) if tail == 2 else (orc.demosaic_ahd(bay, wb, M, False, stages) if q == 2 else orc.demosaic_eag(bay, wb) if q == 1 else orc.demosaic_draft(bay, wb))
                 assert np.array_equal(whole, want), (case, "oracle")
         # negative control: with the halo starved (PYSP_BAND_HALO_DELTA, a test-only switch) the same comparison must FAIL on noise -- the bands are really cut
         os.environ["PYSP_BAND_HALO_DELTA"] = "-6"
+        os.environ.pop("PYSP_BAND_FIRST_PX", None); os.environ.pop("PYSP_BAND_CAP_PX", None)
         os.environ["PYSP_BAND_ROWS"] = "16"
         H, W = 96, 64
         bay = rng.random((H, W)).astype(np.float32)
