@@ -763,10 +763,21 @@ static int run_chain_t(pysp_ctx* ctx, const T* const* bayers, const float* black
         for (int i = 0; i < 2; i++) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
     }
     auto mosaic = [&](const T* d) { return sizeof(T) == 2 ? mosaic_u16(reinterpret_cast<const uint16_t*>(d), black, sat) : mosaic_f32(reinterpret_cast<const float*>(d)); };
+    // Every way out of this function -- also an early error return in the middle of the chain -- first lets the three streams drain: the transfers read and
+    // write the CALLER's memory, and the caller's page locks go when this function returns (the regular path has drained them already: no cost there).
+    struct Drain {
+        pysp_ctx* c;
+        ~Drain() {
+            hipError_t e = hipStreamSynchronize(c->up_stream); (void)e;
+            e = hipStreamSynchronize(c->stream); (void)e;
+            e = hipStreamSynchronize(c->copy_stream); (void)e;
+        }
+    } drain{ctx};
     // The host runs ahead of the device by `depth` bands at most (default 2: it enqueues band g once band g-2 has landed; the two buffer pairs allow two bands
-    // in flight anyway, and band g's upload + kernels, 0.15 ms, fit inside band g-1's download, 0.32 ms).  Enqueueing further ahead makes this runtime SLOWER,
-    // not faster -- measured at 24 MP, 8 frames, ms per frame (tools/batch_probe.py): depth 2 / 3: 5.80, 4: 10.1, 8: 27.2, 16: 12.6, no limit: 16-24 -- while the
-    // single call (16 bands, no limit, one drain per frame) takes 5.93.  PYSP_BATCH_DEPTH overrides.
+    // in flight anyway, and band g's upload + kernels fit inside band g-1's download: band_schedule).  Enqueueing further ahead makes this runtime SLOWER, not
+    // faster -- measured at 24 MP with 16 uniform bands per frame, 8 frames, ms per frame (tools/batch_probe.py): depth 2 / 3: 5.80, 4: 10.1, 8: 27.2, 16: 12.6, no
+    // limit: 16-24; and one 100 MP frame on an unthrottled chain: 23 or 40-70 ms depending on the band count (profiles/r5_band_ramp_probe_unthrottled.log).
+    // PYSP_BATCH_DEPTH overrides.
     static const int depth_env = [] { const char* e = getenv("PYSP_BATCH_DEPTH"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : v > pysp_ctx::RING ? pysp_ctx::RING : v; }();
     const int depth = depth_env ? depth_env : 2;
     for (int i = 0; i < pysp_ctx::RING; i++) if (!ctx->ev_ring[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_ring[i], hipEventDisableTiming));
