@@ -82,9 +82,10 @@ def debayer_batch(images, quality, postprocess_stages: int = 1, to: str = "image
     Mf = final_matrix(mat)
     hdr = bool(first.get_hdr())
     mosaics = []
+    shape0 = np.shape(first.sensor_scaled)
     for im in images:
         b = _lib.f32c(im.sensor_scaled)
-        if b.ndim != 2 or b.shape != _lib.f32c(first.sensor_scaled).shape:
+        if b.ndim != 2 or b.shape != shape0:
             raise ValueError("debayer_batch: every frame must be a 2-D mosaic of the first frame's size")
         if b.shape[0] < 2 or b.shape[1] < 2 or b.shape[0] % 2 or b.shape[1] % 2:
             raise ValueError("demosaic: mosaic dimensions must be even and >= 2 (got %dx%d)" % b.shape)

@@ -39,3 +39,29 @@ def test_host_team_copies(monkeypatch):
     assert _hostpar.team() == 1
     monkeypatch.delenv("PYSP_HOST_THREADS")
     assert 1 <= _hostpar.team() <= 16
+
+
+def test_debayer_batch_argument_checks_need_no_gpu():
+    """debayer_batch (round 5; not part of the reference's API) validates before it touches the library: mixed geometries / camera parameters raise ValueError,
+    an unknown quality NotImplementedError (like image.py:176), an empty batch is an empty list."""
+    import pytest
+    from pysp_amd.const import QualityDemosaic
+    from pysp_amd.debayer import debayer_batch
+    from pysp_amd.image import RawRggbBayerData
+    from pysp_amd.synth import default_wb, rggb_frame
+    wb = default_wb()
+    a, b = RawRggbBayerData(rggb_frame(8, 8, 1), wb, 10.0, 1.0), RawRggbBayerData(rggb_frame(8, 10, 1), wb, 10.0, 1.0)
+    assert debayer_batch([], QualityDemosaic.Best) == []
+    with pytest.raises(ValueError):
+        debayer_batch([a, b], QualityDemosaic.Best)
+    with pytest.raises(ValueError):
+        debayer_batch([a], QualityDemosaic.Best, to="xyz")
+    with pytest.raises(NotImplementedError):
+        debayer_batch([a], 9)
+    class OtherWb:                                            # cam_wb is duck-typed on this path (SURVEY.md section 8b): another white balance, same matrix
+        def get_reciprocal_multipliers(self): return (wb.get_reciprocal_multipliers() * np.float32(1.25)).astype(np.float32)
+        def get_matrix(self): return wb.get_matrix()
+        def copy(self): return self
+    c = RawRggbBayerData(rggb_frame(8, 8, 2), OtherWb(), 10.0, 1.0)
+    with pytest.raises(ValueError):
+        debayer_batch([a, c], QualityDemosaic.Fast)
