@@ -189,7 +189,8 @@ class DevicePipeline:
                                                 float(centre[0]), float(centre[1]), float(scale), int(row0), int(row1), ctypes.byref(s0), ctypes.byref(s1)))
         return s0.value, s1.value
 
-    def demosaic_warp(self, bayer, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0):
-        """BASELINE config 5 on one GPU: AHD(postprocess_stages) then per-channel WarpRectilinear."""
-        rgb = self.demosaic(bayer, wb, M, _lib.QUALITY_BEST, False, stages)
-        return self.warp(rgb, coeffs, centre, scale)
+    def demosaic_warp(self, bayer, wb, M, coeffs, centre, stages: int = 3, scale: float = 1.0, rgb=None, out=None):
+        """BASELINE config 5 on one GPU: AHD(postprocess_stages) then per-channel WarpRectilinear.  `rgb` / `out`: optional reusable (H, W, 3) device
+        buffers for the demosaiced and the warped frame (1.2 GB each at 100 MP: a caller that streams frames keeps them)."""
+        rgb = self.demosaic(bayer, wb, M, _lib.QUALITY_BEST, False, stages, out=rgb)
+        return self.warp(rgb, coeffs, centre, scale, out=out)

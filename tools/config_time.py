@@ -35,5 +35,6 @@ torch.cuda.empty_cache()
 H, W = 8736, 11648
 bay = torch.from_numpy(rggb_frame(H, W, 1001)).cuda()
 coeffs = np.array([[1.0, 0.01, 0.002, 0, 0, 0], [1.0, 0.0, 0.002, 0, 0, 0], [1.0, -0.01, 0.002, 0, 0, 0]])
-ms = timed(lambda: pipe.demosaic_warp(bay, wb, M, coeffs, (0.5, 0.5), stages=3), reps=3)
+rgb5, out5 = torch.empty((bay.shape[0], bay.shape[1], 3), dtype=torch.float32, device="cuda"), torch.empty((bay.shape[0], bay.shape[1], 3), dtype=torch.float32, device="cuda")
+ms = timed(lambda: pipe.demosaic_warp(bay, wb, M, coeffs, (0.5, 0.5), stages=3, rgb=rgb5, out=out5), reps=3)
 print("config 5 on 1 GPU (100 MP AHD(3) + warp): %.2f ms = %.1f GMP/s" % (ms, H * W / 1e9 / (ms * 1e-3)))
